@@ -1,0 +1,184 @@
+/*
+ * mmgl_hip.h -- C ABI of libmmgl_hip.so: the MI355X (gfx950) kernels behind MMGL's
+ * neighbor-fusion hot path.
+ *
+ * The reference (minjiyoon/MMGL) has no FFI: the path sits behind a Python module API
+ * (SURVEY.md 8b).  Each entry point below replaces a run of stock ATen ops inside one reference
+ * function; the citation after "replaces:" is reference file:line.  The Python binding that a
+ * maintainer of the reference would add is in INTEGRATION.md (ctypes, one torch.autograd.Function
+ * per fwd/bwd pair).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated inside; scratch
+ *     is passed explicitly (query the size with the matching *_workspace function).
+ *   - tensors are dense row-major in the layout given in the comment.
+ *   - dtype: element type of the activations (MMGL_F32 / MMGL_BF16); reductions, softmax and
+ *     accumulation are always fp32.
+ *   - last argument: the hipStream_t to launch on, passed as void* (0 = default stream).
+ *   - returns 0 on success, otherwise an MMGL_ERR_* code; mmgl_last_error() gives the message.
+ *     The Python shim maps INVALID/UNSUPPORTED to ValueError (the reference raises ValueError for
+ *     shape / mode mismatches, modelling_cross_attention.py:160-164,214-224,260-264) and HIP to
+ *     RuntimeError.
+ *   - re-entrant; no global state except the last-error string (thread-local).
+ */
+#ifndef MMGL_HIP_H
+#define MMGL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MMGL_F32 = 0, MMGL_BF16 = 1 };
+enum { MMGL_OK = 0, MMGL_ERR_INVALID = 1, MMGL_ERR_UNSUPPORTED = 2, MMGL_ERR_HIP = 3 };
+enum { MMGL_ACT_NONE = 0, MMGL_ACT_RELU = 1 };
+
+const char* mmgl_last_error(void);
+int mmgl_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Masked cross-attention core:  O = softmax(max(Q K^T + M, finfo.min)) V   per (batch, head)
+ * replaces: MPTAttention.forward, model/modelling_cross_attention.py:206-271 (head split, bmm,
+ *           additive mask + clamp, softmax, bmm, head merge) and _expand_mask :68-79 (the
+ *           [B,1,T,S] additive mask is never materialised: the [B,S] byte mask is consumed).
+ *   q         [B,T,H*D]  already projected AND scaled by D^-0.5 (:194)
+ *   k, v      [B,S,H*D]  projected neighbor tokens (:198-199)
+ *   key_valid [B,S] uint8, 1 = attend (neighbor pos_id > 0, :1077/:1084-1104)
+ *   out       [B,T,H*D]
+ *   lse       [B,H,T] fp32 log-sum-exp of the masked scores (saved for backward)
+ * A sample with no valid key yields the uniform distribution over its S keys (the reference's
+ * finfo.min clamp, :226-228), never NaN.  D in {16,32,64,128}; S <= 256.
+ * p_drop must be 0 (OPT's attention_dropout is 0.0; :256 is then the identity).
+ */
+int mmgl_xattn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid,
+                   void* out, float* lse, int B, int H, int T, int S, int D,
+                   float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream);
+
+/* Backward of the above.  dq [B,T,H*D], dk/dv [B,S,H*D].  `workspace` must hold
+ * mmgl_xattn_bwd_workspace(...) bytes (fp32 row-dots + per-chunk dK/dV partials, reduced in a
+ * fixed order => bitwise deterministic).  On a sample with no valid key dQ/dK are halved exactly
+ * as autograd does for the reference's torch.max tie (see oracle/lm_ref.py attention_core). */
+size_t mmgl_xattn_bwd_workspace(int B, int H, int T, int S, int D);
+int mmgl_xattn_bwd(const void* dout, const void* q, const void* k, const void* v, const float* lse,
+                   const uint8_t* key_valid, void* dq, void* dk, void* dv,
+                   void* workspace, size_t workspace_bytes,
+                   int B, int H, int T, int S, int D, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm (affine, eps inside the sqrt) over the last dim.
+ * replaces: nn.LayerNorm at modelling_cross_attention.py:319-320, 340-341, 349-350, 364-365, 635-636
+ *   x,y [rows,cols]; gamma,beta [cols] (same dtype as x; may be NULL = no affine); mean,rstd [rows] fp32
+ */
+int mmgl_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                       int rows, int cols, float eps, int dtype, void* stream);
+/* dgamma/dbeta are fp32 [cols] (may be NULL for a frozen norm); workspace >= mmgl_norm_bwd_workspace bytes. */
+size_t mmgl_norm_bwd_workspace(int rows, int cols);
+int mmgl_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                       void* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                       int rows, int cols, int dtype, void* stream);
+
+/* RMSNorm  y = x * rsqrt(mean(x^2)+eps) * gamma   (Llama variant of the same block; no reference
+ * counterpart in MMGL -- SURVEY.md 7.3 "config 5") */
+int mmgl_rmsnorm_fwd(const void* x, const void* gamma, void* y, float* rstd,
+                     int rows, int cols, float eps, int dtype, void* stream);
+int mmgl_rmsnorm_bwd(const void* dy, const void* x, const void* gamma, const float* rstd,
+                     void* dx, float* dgamma, void* workspace, size_t workspace_bytes,
+                     int rows, int cols, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gated residual:  y = residual + tanh(gate) * dropout(x, p)
+ * replaces: nn.functional.dropout + "residual + tanh(gating) * h", modelling_cross_attention.py:332-335, 356-359
+ *   residual,x,y [n] ; gate: device fp32 scalar (NULL => ungated, tanh(gate) := 1, :337/:361)
+ *   dropout mask is a counter-based hash of (seed, element index): regenerated in backward.
+ */
+int mmgl_gated_residual_fwd(const void* residual, const void* x, const float* gate, void* y,
+                            size_t n, float p_drop, uint64_t seed, int dtype, void* stream);
+/* dres = dy (caller aliases it); dx = tanh(g)*mask*dy ; dgate (fp32 scalar, OVERWRITTEN) =
+ * (1-tanh^2 g) * sum(dy * dropout(x)).  workspace >= mmgl_gated_residual_bwd_workspace(n). */
+size_t mmgl_gated_residual_bwd_workspace(size_t n);
+int mmgl_gated_residual_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate,
+                            void* workspace, size_t workspace_bytes,
+                            size_t n, float p_drop, uint64_t seed, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Linear with fused epilogue:  y[M,N] = act( (x[M,K] @ W[N,K]^T + bias[N]) * out_scale )
+ * replaces: nn.Linear q/k/v/out_proj (:194,198-199,273; out_scale = D^-0.5 for q_proj), fc1+ReLU, fc2 (:352-355)
+ *   W is torch's nn.Linear layout [out_features, in_features]; bias may be NULL.
+ * MFMA: bf16 -> v_mfma_f32_16x16x32_bf16 ; f32 -> v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).
+ */
+int mmgl_linear_fwd(const void* x, const void* W, const void* bias, void* y,
+                    int M, int N, int K, int act, float out_scale, int dtype, void* stream);
+/* dx[M,K] = dyp[M,N] @ W[N,K]   where dyp = dy * out_scale * act'(y)   (y = forward OUTPUT; NULL if act none).
+ * workspace (>= mmgl_linear_dgrad_workspace bytes) holds W^T and, with an activation, dyp. N must be a multiple of 8. */
+size_t mmgl_linear_dgrad_workspace(int M, int N, int K, int act, int dtype);
+int mmgl_linear_dgrad(const void* dy, const void* y, const void* W, void* dx, void* workspace, size_t workspace_bytes,
+                      int M, int N, int K, int act, float out_scale, int dtype, void* stream);
+/* dW[N,K] (+)= dyp^T @ x ; dbias[N] (+)= colsum(dyp) ; both in the activation dtype; accumulate!=0 adds to
+ * the existing contents (gradient accumulation across micro-batches). dbias may be NULL.
+ * workspace (>= mmgl_linear_wgrad_workspace bytes) holds dyp^T and x^T. */
+size_t mmgl_linear_wgrad_workspace(int M, int N, int K, int dtype);
+int mmgl_linear_wgrad(const void* dy, const void* y, const void* x, void* dW, void* dbias, void* workspace,
+                      size_t workspace_bytes, int M, int N, int K, int act, float out_scale, int accumulate,
+                      int dtype, void* stream);
+/* out[C,ld] = in[R,C]^T, ld = R rounded up to a whole 16-byte chunk (zero padded) */
+int mmgl_transpose(const void* in, void* out, int R, int C, int dtype, void* stream);
+
+/* LoRA-fused linear:  y = x W^T + bias + scale * (x A^T) B^T        A [r,K], Bm [N,r]
+ * (peft semantics, lora_dropout = 0; replaces peft's LoRA Linear injected at
+ *  model/modelling_self_attention.py:80-87 -- third-party, parity unpinned)
+ *   xa [M,r] scratch/output in the activation dtype (saved for backward). */
+int mmgl_lora_linear_fwd(const void* x, const void* W, const void* bias, const void* A, const void* Bm,
+                         void* y, void* xa, int M, int N, int K, int r, float scale, int dtype, void* stream);
+/* dx = dy W + scale * (dy Bm) A ; dA = scale * (dy Bm)^T x ; dB = scale * dy^T xa.  dyb [M,r] scratch/output. */
+size_t mmgl_lora_linear_bwd_workspace(int M, int N, int K, int r, int dtype);
+int mmgl_lora_linear_bwd(const void* dy, const void* x, const void* xa, const void* W, const void* A,
+                         const void* Bm, void* dx, void* dA, void* dB, void* dyb, void* workspace,
+                         size_t workspace_bytes, int M, int N, int K, int r, float scale, int accumulate,
+                         int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Neighbor interleave: scatter text / image neighbor tokens into slot order + build the key mask.
+ * replaces: CrossAttentionModel.forward, modelling_cross_attention.py:1084-1104 (zeros + index_put x4)
+ *   text_emb [B,Nt,n_tok*d], vis_emb [B,Ni,n_tok*d] (vis_emb may be NULL with Ni = 0: text_only :1075-1078)
+ *   text_loc/img_loc, text_pos/img_pos: int64 [B,Nt] / [B,Ni]
+ *   out_emb [B,(Nt+Ni)*n_tok,d] ; out_valid [B,(Nt+Ni)*n_tok] uint8.  Slots nobody writes stay zero/invalid.
+ */
+int mmgl_neighbor_interleave_fwd(const void* text_emb, const void* vis_emb, const int64_t* text_loc,
+                                 const int64_t* img_loc, const int64_t* text_pos, const int64_t* img_pos,
+                                 void* out_emb, uint8_t* out_valid, int B, int Nt, int Ni, int n_tok, int d,
+                                 int dtype, void* stream);
+int mmgl_neighbor_interleave_bwd(const void* d_out_emb, const int64_t* text_loc, const int64_t* img_loc,
+                                 void* d_text_emb, void* d_vis_emb, int B, int Nt, int Ni, int n_tok, int d,
+                                 int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Shifted token cross-entropy over [rows, V] logits (mean over rows whose label != ignore_index).
+ * replaces: CrossEntropyLoss at modelling_cross_attention.py:831-836 (the shift is done by the caller's
+ * pointer arithmetic: row r of `logits` is scored against labels[r]).
+ *   loss_sum, count: fp32 device scalars (OVERWRITTEN); row_lse, row_loss [rows] fp32 (row_lse saved for backward).
+ *   bwd writes dlogits = (softmax - onehot) * (*dloss_scale) / count, zero on ignored rows.
+ */
+int mmgl_cross_entropy_fwd(const void* logits, const int64_t* labels, float* row_lse, float* row_loss,
+                           float* loss_sum, float* count, int rows, int V, int64_t ignore_index, int dtype,
+                           void* stream);
+int mmgl_cross_entropy_bwd(const void* logits, const int64_t* labels, const float* row_lse,
+                           const float* count, const float* dloss, void* dlogits,
+                           int rows, int V, int64_t ignore_index, int dtype, void* stream);
+
+/* Learned-position ids: pos[b,t] = cumsum(mask)[b,t]*mask[b,t] - 1 + 2
+ * replaces: MPTLearnedPositionalEmbedding.forward, modelling_cross_attention.py:135-145 */
+int mmgl_position_ids(const int64_t* attention_mask, int64_t* pos, int B, int T, void* stream);
+
+/* Fused AdamW step over a flat parameter bucket (torch.optim.AdamW semantics, run_generation.py:327-330).
+ * param/grad in `dtype`; exp_avg/exp_avg_sq fp32; master (fp32 copy of param) may be NULL. grad is read * grad_scale. */
+int mmgl_adamw_step(void* param, float* master, const void* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    float grad_scale, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMGL_HIP_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of libmmgl_hip.so (C ABI in include/mmgl_hip.h).
+
+The library must exist: there is NO CPU / eager fallback anywhere in this package.  A missing or
+unloadable .so raises at first use, loudly.
+"""
+import ctypes
+import os
+
+import torch  # imported first on purpose: the .so must bind to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmgl_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+_ERR_INVALID, _ERR_UNSUPPORTED, _ERR_HIP = 1, 2, 3
+
+c_void_p, c_int, c_float, c_size_t, c_u64, c_i64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
+                                                    ctypes.c_uint64, ctypes.c_int64)
+P, I, F, Z, U, L = c_void_p, c_int, c_float, c_size_t, c_u64, c_i64
+
+# name -> (restype, argtypes); every symbol include/mmgl_hip.h declares
+SIGNATURES = {
+    "mmgl_last_error": (ctypes.c_char_p, []),
+    "mmgl_version": (I, []),
+    "mmgl_xattn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, U, U, I, P]),
+    "mmgl_xattn_bwd_workspace": (Z, [I, I, I, I, I]),
+    "mmgl_xattn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, P]),
+    "mmgl_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, I, P]),
+    "mmgl_norm_bwd_workspace": (Z, [I, I]),
+    "mmgl_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, I, P]),
+    "mmgl_rmsnorm_fwd": (I, [P, P, P, P, I, I, F, I, P]),
+    "mmgl_rmsnorm_bwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, P]),
+    "mmgl_gated_residual_fwd": (I, [P, P, P, P, Z, F, U, I, P]),
+    "mmgl_gated_residual_bwd_workspace": (Z, [Z]),
+    "mmgl_gated_residual_bwd": (I, [P, P, P, P, P, P, Z, Z, F, U, I, P]),
+    "mmgl_linear_fwd": (I, [P, P, P, P, I, I, I, I, F, I, P]),
+    "mmgl_linear_dgrad_workspace": (Z, [I, I, I, I, I]),
+    "mmgl_linear_dgrad": (I, [P, P, P, P, P, Z, I, I, I, I, F, I, P]),
+    "mmgl_linear_wgrad_workspace": (Z, [I, I, I, I]),
+    "mmgl_linear_wgrad": (I, [P, P, P, P, P, P, Z, I, I, I, I, F, I, I, P]),
+    "mmgl_transpose": (I, [P, P, I, I, I, P]),
+    "mmgl_lora_linear_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P]),
+    "mmgl_lora_linear_bwd_workspace": (Z, [I, I, I, I, I]),
+    "mmgl_lora_linear_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, F, I, I, P]),
+    "mmgl_neighbor_interleave_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "mmgl_neighbor_interleave_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
+    "mmgl_cross_entropy_fwd": (I, [P, P, P, P, P, P, I, I, L, I, P]),
+    "mmgl_cross_entropy_bwd": (I, [P, P, P, P, P, P, I, I, L, I, P]),
+    "mmgl_position_ids": (I, [P, P, I, I, P]),
+    "mmgl_adamw_step": (I, [P, P, P, P, P, Z, F, F, F, F, F, I, F, I, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m mmgl_amd._build` "
+                "(or __graft_entry__.build()). mmgl_amd has no CPU fallback.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc == 0:
+        return
+    msg = lib().mmgl_last_error().decode("utf-8", "replace")
+    if rc in (_ERR_INVALID, _ERR_UNSUPPORTED):
+        raise ValueError(msg or what)
+    raise RuntimeError(msg or what)
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise ValueError(f"mmgl_amd kernels take float32 or bfloat16 activations, got {t.dtype}")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mmgl_amd ops run on the GPU only (tensor is on %s); there is no CPU path" % t.device)

@@ -1,0 +1,408 @@
+// Dense projections of the gated cross-attention block on MFMA (gfx950):
+//   y = act((x W^T + bias) * scale)  [+ second operand pair for the fused LoRA term],  dgrad, wgrad.
+// replaces nn.Linear q/k/v/out_proj, fc1(+ReLU), fc2 of reference model/modelling_cross_attention.py:194-199,273,352-355
+// and peft's LoRA linear (model/modelling_self_attention.py:80-87).
+//
+// One kernel: "NT" GEMM  C[M,N] = X[M,K] . W[N,K]^T  -- both operands contraction-contiguous, which is exactly
+// torch's nn.Linear layout, so forward needs no transposes.  128x128 block tile, K step = 128 bytes per row
+// (64 bf16 / 32 f32), 4 waves as 2x2, each wave 64x64 = 4x4 v_mfma 16x16 tiles (bf16: 16x16x32; f32: 8 x 16x16x4,
+// an exact fp32 fma chain).  Operands are staged global -> VGPR -> LDS with the next tile's loads issued before
+// the current tile's MFMAs (double-buffered LDS, one barrier per K tile); LDS rows are 128 B with the 16-B slot
+// XOR-swizzled by (row>>1)&7 so a fragment read (16 lanes = 16 rows, same k-slot) is bank-conflict free.
+// W is the MFMA A operand and X the B operand, so each lane ends up with 4 CONSECUTIVE output columns of one
+// output row: bias add, activation and the 8/16-byte stores need no cross-lane traffic.
+// dgrad / wgrad are the same kernel on explicitly transposed operands (tile transpose kernel below); the ReLU
+// mask, the out_scale and the bias column-sum are fused into that transpose / mask pass.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, ROWB = 128;         // tile rows (x side), tile rows (W side), bytes per LDS row
+constexpr int TILE_BYTES = BM * ROWB;                 // 16 KiB per operand per buffer
+
+template <typename T> struct GT {
+    static constexpr int VN = 16 / sizeof(T);         // elements per 16-B chunk
+    static constexpr int BK = ROWB / sizeof(T);       // 64 bf16 / 32 f32
+    static constexpr int KSTEPS = BK / 32;            // 32-wide MFMA contraction steps per tile
+    typedef T chunk_t __attribute__((ext_vector_type(16 / sizeof(T))));
+};
+
+__device__ __forceinline__ int swz(int row, int c) { return row * ROWB + ((c ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T> __device__ __forceinline__ typename Elem<T>::v8 lds_frag(const char* tile, int row, int ks, int g);
+template <> __device__ __forceinline__ bf16x8 lds_frag<bf16>(const char* tile, int row, int ks, int g) {
+    return *(const bf16x8*)(tile + swz(row, ks * 4 + g));
+}
+template <> __device__ __forceinline__ f32x8 lds_frag<float>(const char* tile, int row, int ks, int g) {
+    const f32x4 a = *(const f32x4*)(tile + swz(row, 2 * g));
+    const f32x4 b = *(const f32x4*)(tile + swz(row, 2 * g + 1));
+    f32x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return r;
+}
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ Y,
+                                                      const T* __restrict__ bias, int M, int N, int K, float scale,
+                                                      int accumulate, const T* __restrict__ X2, const T* __restrict__ W2,
+                                                      int K2, int tiles_m, int tiles_n) {
+    typedef GT<T> G;
+    typedef typename G::chunk_t chunk_t;
+    typedef typename Elem<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;                       // [2][TILE_BYTES]
+    char* sW = smem + 2 * TILE_BYTES;      // [2][TILE_BYTES]
+
+    // XCD-aware tile order: consecutive virtual ids share the W panel (same tile_n) on one XCD's L2
+    const int vid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tn = vid / tiles_m, tm = vid % tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 15, g = lane >> 4;
+    const int wn = wave >> 1, wm = wave & 1;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = vzero<f32x4>();
+
+    const int nk1 = (K + G::BK - 1) / G::BK;
+    const int nk2 = X2 ? (K2 + G::BK - 1) / G::BK : 0;
+    const int nk = nk1 + nk2;
+
+    chunk_t rx[4], rw[4];
+    auto load_tile = [&](int kt) {
+        const T* xs = X; const T* ws = W; int kk = K, k0 = kt * G::BK;
+        if (kt >= nk1) { xs = X2; ws = W2; kk = K2; k0 = (kt - nk1) * G::BK; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256, row = id >> 3, c = id & 7;
+            const int kc = k0 + c * G::VN;
+            rx[i] = (m0 + row < M && kc < kk) ? *(const chunk_t*)(xs + (size_t)(m0 + row) * kk + kc) : vzero<chunk_t>();
+            rw[i] = (n0 + row < N && kc < kk) ? *(const chunk_t*)(ws + (size_t)(n0 + row) * kk + kc) : vzero<chunk_t>();
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256, row = id >> 3, c = id & 7;
+            *(chunk_t*)(sX + buf * TILE_BYTES + swz(row, c)) = rx[i];
+            *(chunk_t*)(sW + buf * TILE_BYTES + swz(row, c)) = rw[i];
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char* tX = sX + buf * TILE_BYTES;
+        const char* tW = sW + buf * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < G::KSTEPS; ++ks) {
+            v8 fw[4], fx[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fw[i] = lds_frag<T>(tW, wn * 64 + i * 16 + x, ks, g);
+                fx[i] = lds_frag<T>(tX, wm * 64 + i * 16 + x, ks, g);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(acc[i][j], fw[i], fx[j]);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane (x = output row within tile j, g) holds columns n = 16 i + 4 g + 0..3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + x;
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + g * 4;
+            if (n >= N) continue;
+            f32x4 v = acc[i][j];
+            if (bias) {
+                const typename Elem<T>::v4 bv = *(const typename Elem<T>::v4*)(bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
+            }
+            v *= scale;
+            if (ACT == MMGL_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            T* yp = Y + (size_t)m * N + n;
+            if (accumulate) {
+                const typename Elem<T>::v4 ov = *(const typename Elem<T>::v4*)yp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
+            }
+            if constexpr (sizeof(T) == 2) *(bf16x4*)yp = __builtin_convertvector(v, bf16x4);
+            else *(f32x4*)yp = v;
+        }
+    }
+}
+
+// out[C,R] = transpose(f(in[R,C])) with f = (* scale) and optional ReLU mask from yact[R,C] (> 0);
+// optional colsum[C] (+)= sum over R of f(in) (fp32 atomics are avoided: one block owns a full column strip).
+// 64x64 tiles through LDS; grid.x = column strips, block loops over all row tiles of its strip.
+template <typename T, bool MASK>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, const T* __restrict__ yact,
+                                                        T* __restrict__ out, T* __restrict__ colsum, int R, int C,
+                                                        int ldo, float scale, int accumulate) {
+    __shared__ float tile[64][65];
+    __shared__ float csum[4][64];
+    const int c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float cs = 0.f;
+    for (int r0 = blockIdx.y * 64; r0 < ldo; r0 += gridDim.y * 64) {
+#pragma unroll 4
+        for (int i = ty; i < 64; i += 4) {
+            const int r = r0 + i, c = c0 + tx;
+            float v = 0.f;
+            if (r < R && c < C) {
+                v = (float)in[(size_t)r * C + c] * scale;
+                if (MASK && !((float)yact[(size_t)r * C + c] > 0.f)) v = 0.f;
+            }
+            tile[i][tx] = v;
+            cs += v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = ty; i < 64; i += 4) {
+            const int c = c0 + i, r = r0 + tx;
+            if (c < C && r < ldo) out[(size_t)c * ldo + r] = (T)tile[tx][i];   // rows R..ldo-1 are zero padding
+        }
+        __syncthreads();
+    }
+    if (colsum && gridDim.y == 1) {
+        csum[ty][tx] = cs;
+        __syncthreads();
+        if (ty == 0 && c0 + tx < C) {
+            float s = csum[0][tx] + csum[1][tx] + csum[2][tx] + csum[3][tx];
+            if (accumulate) s += (float)colsum[c0 + tx];
+            colsum[c0 + tx] = (T)s;
+        }
+    }
+}
+
+// dyp = dy * scale * (y > 0)
+template <typename T>
+__global__ __launch_bounds__(256) void relu_mask_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ out,
+                                                        size_t n, float scale) {
+    typedef typename GT<T>::chunk_t V;
+    constexpr int VN = GT<T>::VN;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n / VN; i += (size_t)gridDim.x * 256) {
+        const V d = ((const V*)dy)[i], a = ((const V*)y)[i];
+        V o;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) o[j] = ((float)a[j] > 0.f) ? (T)((float)d[j] * scale) : (T)0.f;
+        ((V*)out)[i] = o;
+    }
+}
+
+template <typename T> inline int pad_k(int k) { return (k + GT<T>::VN - 1) / GT<T>::VN * GT<T>::VN; }
+
+template <typename T>
+int launch_gemm(const T* X, const T* W, T* Y, const T* bias, int M, int N, int K, int act, float scale, int accumulate,
+                const T* X2, const T* W2, int K2, hipStream_t st) {
+    constexpr int VN = GT<T>::VN;
+    MMGL_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: M,N,K must be positive (got %d,%d,%d)", M, N, K);
+    if (K % VN || N % 4 || (X2 && K2 % VN))
+        MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm: K (%d) must be a multiple of %d and N (%d) of 4", K, VN, N);
+    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+    const size_t lds = 4 * TILE_BYTES;
+    auto k0 = gemm_nt_kernel<T, MMGL_ACT_NONE>;
+    auto k1 = gemm_nt_kernel<T, MMGL_ACT_RELU>;
+    auto kern = act == MMGL_ACT_RELU ? k1 : k0;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, st, X, W, Y, bias, M, N, K, scale, accumulate, X2, W2, K2,
+                       tiles_m, tiles_n);
+    MMGL_CHECK_LAUNCH("gemm_nt");
+    return MMGL_OK;
+}
+
+template <typename T>
+int launch_transpose(const T* in, const T* yact, T* out, T* colsum, int R, int C, float scale, int accumulate, hipStream_t st) {
+    const int ldo = pad_k<T>(R);   // the transposed matrix becomes a GEMM operand: its rows must be whole 16-B chunks
+    dim3 grid(cdiv(C, 64), colsum ? 1 : (cdiv(ldo, 64) > 64 ? 64 : cdiv(ldo, 64)));
+    if (yact) hipLaunchKernelGGL((transpose_kernel<T, true>), grid, dim3(256), 0, st, in, yact, out, colsum, R, C, ldo, scale, accumulate);
+    else hipLaunchKernelGGL((transpose_kernel<T, false>), grid, dim3(256), 0, st, in, yact, out, colsum, R, C, ldo, scale, accumulate);
+    MMGL_CHECK_LAUNCH("transpose");
+    return MMGL_OK;
+}
+
+template <typename T>
+int linear_dgrad(const T* dy, const T* y, const T* W, T* dx, char* ws, int M, int N, int K, int act, float scale, hipStream_t st) {
+    // ws: W^T [K,N] | dyp [M,N] (only with an activation)
+    if (N % GT<T>::VN) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "linear_dgrad: out_features %d must be a multiple of %d", N, GT<T>::VN);
+    T* Wt = (T*)ws;
+    T* dyp = (T*)(ws + align_up((size_t)K * ((size_t)(N + 7) / 8 * 8) * sizeof(T), 256));
+    int rc = launch_transpose<T>(W, nullptr, Wt, nullptr, N, K, 1.f, 0, st);
+    if (rc) return rc;
+    const T* a = dy;
+    float s = scale;
+    if (act == MMGL_ACT_RELU) {
+        size_t n = (size_t)M * N;
+        int blocks = (int)((n / GT<T>::VN + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(relu_mask_kernel<T>, dim3(blocks), dim3(256), 0, st, dy, y, dyp, n, scale);
+        MMGL_CHECK_LAUNCH("relu_mask");
+        a = dyp;
+        s = 1.f;
+    }
+    return launch_gemm<T>(a, Wt, dx, nullptr, M, K, N, MMGL_ACT_NONE, s, 0, nullptr, nullptr, 0, st);   // N % 8 == 0 checked by caller
+}
+
+template <typename T>
+int linear_wgrad(const T* dy, const T* y, const T* x, T* dW, T* dbias, char* ws, int M, int N, int K, int act, float scale,
+                 int accumulate, hipStream_t st) {
+    // ws: dyp^T [N,M] | x^T [K,M]
+    T* dyT = (T*)ws;
+    T* xT = (T*)(ws + align_up((size_t)N * ((size_t)(M + 7) / 8 * 8) * sizeof(T), 256));
+    int rc = launch_transpose<T>(dy, act == MMGL_ACT_RELU ? y : nullptr, dyT, dbias, M, N, scale, accumulate, st);
+    if (rc) return rc;
+    rc = launch_transpose<T>(x, nullptr, xT, nullptr, M, K, 1.f, 0, st);
+    if (rc) return rc;
+    return launch_gemm<T>(dyT, xT, dW, nullptr, N, K, pad_k<T>(M), MMGL_ACT_NONE, 1.f, accumulate, nullptr, nullptr, 0, st);
+}
+
+size_t dgrad_ws(int M, int N, int K, int act, size_t esz) {
+    const size_t Np = (size_t)(N + 7) / 8 * 8;
+    return align_up((size_t)K * Np * esz, 256) + (act ? align_up((size_t)M * N * esz, 256) : 0);
+}
+size_t wgrad_ws(int M, int N, int K, size_t esz) {
+    const size_t Mp = (size_t)(M + 7) / 8 * 8;
+    return align_up((size_t)N * Mp * esz, 256) + align_up((size_t)K * Mp * esz, 256);
+}
+
+template <typename T>
+int lora_fwd(const T* x, const T* W, const T* bias, const T* A, const T* Bm, T* y, T* xa, int M, int N, int K, int r,
+             float scale, hipStream_t st) {
+    // xa = scale * x A^T ; y = [x | xa] . [W | Bm]^T + bias  (the LoRA term rides in the same accumulators)
+    int rc = launch_gemm<T>(x, A, xa, nullptr, M, r, K, MMGL_ACT_NONE, scale, 0, nullptr, nullptr, 0, st);
+    if (rc) return rc;
+    return launch_gemm<T>(x, W, y, bias, M, N, K, MMGL_ACT_NONE, 1.f, 0, xa, Bm, r, st);
+}
+
+template <typename T>
+int lora_bwd(const T* dy, const T* x, const T* xa, const T* W, const T* A, const T* Bm, T* dx, T* dA, T* dB, T* dyb,
+             char* ws, int M, int N, int K, int r, float scale, int accumulate, hipStream_t st) {
+    // ws: W^T [K,N] | A^T [K,r] | Bm^T [r,N] | dy^T [N,M] | x^T [K,M] | xa^T [r,M] | dyb^T [r,M]
+    if (N % GT<T>::VN || r % GT<T>::VN)
+        MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "lora_bwd: out_features %d and rank %d must be multiples of %d", N, r, GT<T>::VN);
+    size_t off = 0;
+    auto take = [&](size_t elems) { T* p = (T*)(ws + off); off += align_up(elems * sizeof(T), 256); return p; };
+    const size_t Np = (size_t)(N + 7) / 8 * 8, rp = (size_t)(r + 7) / 8 * 8;
+    T* Wt = take((size_t)K * Np); T* At = take((size_t)K * rp); T* Bt = take((size_t)r * Np);
+    const size_t Mp = (size_t)(M + 7) / 8 * 8;
+    T* dyT = take((size_t)N * Mp); T* xT = take((size_t)K * Mp); T* xaT = take((size_t)r * Mp); T* dybT = take((size_t)r * Mp);
+    int rc;
+    if ((rc = launch_transpose<T>(W, nullptr, Wt, nullptr, N, K, 1.f, 0, st))) return rc;
+    if ((rc = launch_transpose<T>(A, nullptr, At, nullptr, r, K, 1.f, 0, st))) return rc;
+    if ((rc = launch_transpose<T>(Bm, nullptr, Bt, nullptr, N, r, 1.f, 0, st))) return rc;
+    // dyb = scale * dy Bm            [M,r]
+    if ((rc = launch_gemm<T>(dy, Bt, dyb, nullptr, M, r, N, MMGL_ACT_NONE, scale, 0, nullptr, nullptr, 0, st))) return rc;
+    // dx = dy W + dyb A              [M,K]
+    if ((rc = launch_gemm<T>(dy, Wt, dx, nullptr, M, K, N, MMGL_ACT_NONE, 1.f, 0, dyb, At, r, st))) return rc;
+    // dA = dyb^T x  [r,K] ; dB = dy^T xa [N,r]   (xa already carries `scale`)
+    if ((rc = launch_transpose<T>(dyb, nullptr, dybT, nullptr, M, r, 1.f, 0, st))) return rc;
+    if ((rc = launch_transpose<T>(x, nullptr, xT, nullptr, M, K, 1.f, 0, st))) return rc;
+    if ((rc = launch_gemm<T>(dybT, xT, dA, nullptr, r, K, pad_k<T>(M), MMGL_ACT_NONE, 1.f, accumulate, nullptr, nullptr, 0, st))) return rc;
+    if ((rc = launch_transpose<T>(dy, nullptr, dyT, nullptr, M, N, 1.f, 0, st))) return rc;
+    if ((rc = launch_transpose<T>(xa, nullptr, xaT, nullptr, M, r, 1.f, 0, st))) return rc;
+    return launch_gemm<T>(dyT, xaT, dB, nullptr, N, r, pad_k<T>(M), MMGL_ACT_NONE, 1.f, accumulate, nullptr, nullptr, 0, st);
+}
+
+size_t lora_ws(int M, int N, int K, int r, size_t esz) {
+    size_t t = 0;
+    const size_t Mp = (size_t)(M + 7) / 8 * 8, Np = (size_t)(N + 7) / 8 * 8, rp = (size_t)(r + 7) / 8 * 8;
+    size_t e[7] = {(size_t)K * Np, (size_t)K * rp, (size_t)r * Np, (size_t)N * Mp, (size_t)K * Mp, (size_t)r * Mp, (size_t)r * Mp};
+    for (int i = 0; i < 7; ++i) t += align_up(e[i] * esz, 256);
+    return t;
+}
+
+}  // namespace
+
+#define DT_SWITCH(who, EXPR_BF16, EXPR_F32)                               \
+    if (dtype == MMGL_BF16) return EXPR_BF16;                             \
+    if (dtype == MMGL_F32) return EXPR_F32;                               \
+    MMGL_FAIL(MMGL_ERR_INVALID, "%s: bad dtype %d", who, dtype)
+
+extern "C" int mmgl_linear_fwd(const void* x, const void* W, const void* bias, void* y, int M, int N, int K, int act,
+                               float out_scale, int dtype, void* stream) {
+    MMGL_CHECK_ARG(x && W && y, "mmgl_linear_fwd: null pointer");
+    MMGL_CHECK_ARG(act == MMGL_ACT_NONE || act == MMGL_ACT_RELU, "mmgl_linear_fwd: unknown activation %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    DT_SWITCH("mmgl_linear_fwd",
+              launch_gemm<bf16>((const bf16*)x, (const bf16*)W, (bf16*)y, (const bf16*)bias, M, N, K, act, out_scale, 0, nullptr, nullptr, 0, st),
+              launch_gemm<float>((const float*)x, (const float*)W, (float*)y, (const float*)bias, M, N, K, act, out_scale, 0, nullptr, nullptr, 0, st));
+}
+
+extern "C" size_t mmgl_linear_dgrad_workspace(int M, int N, int K, int act, int dtype) {
+    return dgrad_ws(M, N, K, act, dtype == MMGL_BF16 ? 2 : 4);
+}
+extern "C" size_t mmgl_linear_wgrad_workspace(int M, int N, int K, int dtype) { return wgrad_ws(M, N, K, dtype == MMGL_BF16 ? 2 : 4); }
+
+extern "C" int mmgl_linear_dgrad(const void* dy, const void* y, const void* W, void* dx, void* workspace, size_t workspace_bytes,
+                                 int M, int N, int K, int act, float out_scale, int dtype, void* stream) {
+    MMGL_CHECK_ARG(dy && W && dx && workspace && (act == MMGL_ACT_NONE || y), "mmgl_linear_dgrad: null pointer");
+    MMGL_CHECK_ARG(workspace_bytes >= mmgl_linear_dgrad_workspace(M, N, K, act, dtype), "mmgl_linear_dgrad: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    DT_SWITCH("mmgl_linear_dgrad",
+              linear_dgrad<bf16>((const bf16*)dy, (const bf16*)y, (const bf16*)W, (bf16*)dx, ws, M, N, K, act, out_scale, st),
+              linear_dgrad<float>((const float*)dy, (const float*)y, (const float*)W, (float*)dx, ws, M, N, K, act, out_scale, st));
+}
+
+extern "C" int mmgl_linear_wgrad(const void* dy, const void* y, const void* x, void* dW, void* dbias, void* workspace,
+                                 size_t workspace_bytes, int M, int N, int K, int act, float out_scale, int accumulate,
+                                 int dtype, void* stream) {
+    MMGL_CHECK_ARG(dy && x && dW && workspace && (act == MMGL_ACT_NONE || y), "mmgl_linear_wgrad: null pointer");
+    MMGL_CHECK_ARG(workspace_bytes >= mmgl_linear_wgrad_workspace(M, N, K, dtype), "mmgl_linear_wgrad: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    DT_SWITCH("mmgl_linear_wgrad",
+              linear_wgrad<bf16>((const bf16*)dy, (const bf16*)y, (const bf16*)x, (bf16*)dW, (bf16*)dbias, ws, M, N, K, act, out_scale, accumulate, st),
+              linear_wgrad<float>((const float*)dy, (const float*)y, (const float*)x, (float*)dW, (float*)dbias, ws, M, N, K, act, out_scale, accumulate, st));
+}
+
+extern "C" int mmgl_lora_linear_fwd(const void* x, const void* W, const void* bias, const void* A, const void* Bm, void* y,
+                                    void* xa, int M, int N, int K, int r, float scale, int dtype, void* stream) {
+    MMGL_CHECK_ARG(x && W && A && Bm && y && xa && r > 0, "mmgl_lora_linear_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    DT_SWITCH("mmgl_lora_linear_fwd",
+              lora_fwd<bf16>((const bf16*)x, (const bf16*)W, (const bf16*)bias, (const bf16*)A, (const bf16*)Bm, (bf16*)y, (bf16*)xa, M, N, K, r, scale, st),
+              lora_fwd<float>((const float*)x, (const float*)W, (const float*)bias, (const float*)A, (const float*)Bm, (float*)y, (float*)xa, M, N, K, r, scale, st));
+}
+
+extern "C" size_t mmgl_lora_linear_bwd_workspace(int M, int N, int K, int r, int dtype) {
+    return lora_ws(M, N, K, r, dtype == MMGL_BF16 ? 2 : 4);
+}
+
+extern "C" int mmgl_lora_linear_bwd(const void* dy, const void* x, const void* xa, const void* W, const void* A,
+                                    const void* Bm, void* dx, void* dA, void* dB, void* dyb, void* workspace,
+                                    size_t workspace_bytes, int M, int N, int K, int r, float scale, int accumulate,
+                                    int dtype, void* stream) {
+    MMGL_CHECK_ARG(dy && x && xa && W && A && Bm && dx && dA && dB && dyb && workspace && r > 0, "mmgl_lora_linear_bwd: bad arguments");
+    MMGL_CHECK_ARG(workspace_bytes >= mmgl_lora_linear_bwd_workspace(M, N, K, r, dtype), "mmgl_lora_linear_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    DT_SWITCH("mmgl_lora_linear_bwd",
+              lora_bwd<bf16>((const bf16*)dy, (const bf16*)x, (const bf16*)xa, (const bf16*)W, (const bf16*)A, (const bf16*)Bm, (bf16*)dx, (bf16*)dA, (bf16*)dB, (bf16*)dyb, ws, M, N, K, r, scale, accumulate, st),
+              lora_bwd<float>((const float*)dy, (const float*)x, (const float*)xa, (const float*)W, (const float*)A, (const float*)Bm, (float*)dx, (float*)dA, (float*)dB, (float*)dyb, ws, M, N, K, r, scale, accumulate, st));
+}
+
+extern "C" int mmgl_transpose(const void* in, void* out, int R, int C, int dtype, void* stream) {
+    MMGL_CHECK_ARG(in && out && R > 0 && C > 0, "mmgl_transpose: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    DT_SWITCH("mmgl_transpose", launch_transpose<bf16>((const bf16*)in, nullptr, (bf16*)out, nullptr, R, C, 1.f, 0, st),
+              launch_transpose<float>((const float*)in, nullptr, (float*)out, nullptr, R, C, 1.f, 0, st));
+}

@@ -1,0 +1,696 @@
+// Masked neighbor cross-attention core for gfx950:  O = softmax(max(QK^T + M, finfo.min)) V
+//
+// Replaces the ATen op chain of MPTAttention.forward (reference model/modelling_cross_attention.py:206-271)
+// plus the materialised [B,1,T,S] additive mask of _expand_mask (:68-79).
+//
+// Shape regime: S = n_neighbors * n_tokens is SHORT (16..128 keys), T is long (640..2176 query
+// rows), D in {64,128}.  The whole K/V of one (batch, head) fits in LDS, so there is no online-softmax loop:
+// one pass, the full score row of a query lives in registers.  The kernel is HBM-bound (AI ~ 58..121 FLOP/B
+// vs a ridge of ~312): what matters is streaming Q in and O out in 16-byte lane accesses with no materialised
+// head transpose; MFMA only does the dense QK^T / PV contractions.
+//
+// Lane geometry (wave64, v_mfma 16x16): lane = (x = l & 15, g = l >> 4).
+//   "swapped" products  S^T = K Q^T  and  O^T = V^T P^T  make every lane own ONE query row (x) and, of that
+//   row, the keys / channels 4g..4g+3 of every 16-block.  Row max / sum = in-lane reduce + two xor-shuffles
+//   (16, 32).  The accumulator layout of S^T is *already* a legal B-operand layout for the second product
+//   (any k-permutation is legal if both operands share it), so P never moves between lanes: the V^T (or K^T)
+//   operand image in LDS is simply stored in the matching key order.
+//
+// LDS images (filled once per workgroup, read by all 4 waves):
+//   row image  R[sb][dc][lane][8] : lane (x,g) -> X[s = 16 sb + x][d = 32 dc + 8 g + 0..7]      (A operand, K or V)
+//   t   image  Tm[db][ks][lane][8]: lane (x,g), e -> X[s = 16(2ks + (e>>2)) + 4g + (e&3)][d = 16 db + x]
+// Both are "fragment linear": a fragment read is one conflict-free ds_read_b128 per lane.
+// fp32 activations skip the t image (LDS budget) and gather it from the row image with scalar reads.
+#include "common.h"
+
+#ifndef MMGL_XATTN_HOIST_MAX
+#define MMGL_XATTN_HOIST_MAX 16
+#endif
+
+namespace {
+
+// QT = 16-row query tiles per iteration: 2 halves the LDS operand traffic per query row but doubles the live
+// accumulators; budget = work_scale (1 fwd, 2 dq) * NSB * NDB 16x16 tiles, fp32 operands cost twice the registers.
+template <typename T, int D_, int NSB_, int WORK_ = 1> struct XC {
+    static constexpr int D = D_;
+    static constexpr int NSB = NSB_;                 // 16-key blocks (S padded to NSB*16)
+    static constexpr int NDC = (D + 31) / 32;        // 32-wide contraction chunks over d
+    static constexpr int DPAD = NDC * 32;
+    static constexpr int NDB = D / 16;               // 16-wide output channel blocks
+    static constexpr int NKS = NSB / 2;              // 32-key contraction steps
+    static constexpr int SPAD = NSB * 16;
+    static constexpr int CPR = DPAD / 8;             // 8-element chunks per (padded) row
+    static constexpr int QT = (WORK_ * NSB_ * (D_ / 16) * (int)(sizeof(T) / 2) <= 32) ? 2 : 1;
+    static constexpr bool TIMG = (sizeof(T) == 2);   // dedicated transposed image (bf16) vs gather (f32)
+    // The K/V operand fragments are loop invariant, so the compiler hoists them into registers when it may
+    // (register-resident K/V, no LDS traffic in the loop).  Past this budget that spills: re-read LDS instead.
+    static constexpr bool HOIST = (WORK_ * NSB_ * (D_ / 16) * (int)(sizeof(T) / 2) <= MMGL_XATTN_HOIST_MAX);
+    static constexpr int ROWIMG = SPAD * DPAD;       // elements
+    static constexpr int TIMGSZ = D * SPAD;          // elements
+};
+
+template <typename C> __device__ __forceinline__ int rf_idx(int sb, int dc, int lane) {
+    return ((sb * C::NDC + dc) * 64 + lane) * 8;
+}
+template <typename C> __device__ __forceinline__ int tf_idx(int db, int ks, int lane) {
+    return ((db * C::NKS + ks) * 64 + lane) * 8;
+}
+
+// Stage X[b, 0..S, h*D .. h*D+D] into a row image (zero padded to SPAD x DPAD).
+template <typename T, typename C>
+__device__ __forceinline__ void stage_row_image(T* img, const T* base, int row_stride, int S) {
+    typedef typename Elem<T>::v8 v8;
+    for (int i = threadIdx.x; i < C::SPAD * C::CPR; i += blockDim.x) {
+        const int s = i / C::CPR, c = i % C::CPR;
+        v8 val = vzero<v8>();
+        if (s < S && c * 8 < C::D) val = *(const v8*)(base + (size_t)s * row_stride + c * 8);
+        *(v8*)(img + rf_idx<C>(s >> 4, c >> 2, (s & 15) + 16 * (c & 3))) = val;
+    }
+}
+// Stage the transposed / key-permuted image.
+template <typename T, typename C>
+__device__ __forceinline__ void stage_t_image(T* img, const T* base, int row_stride, int S) {
+    typedef typename Elem<T>::v8 v8;
+    for (int i = threadIdx.x; i < C::SPAD * (C::D / 8); i += blockDim.x) {
+        const int s = i / (C::D / 8), c = i % (C::D / 8);
+        v8 val = vzero<v8>();
+        if (s < S) val = *(const v8*)(base + (size_t)s * row_stride + c * 8);
+        const int ks = s >> 5, e = (((s & 31) >> 4) << 2) + (s & 3), g = (s & 15) >> 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = c * 8 + j;
+            img[tf_idx<C>(d >> 4, ks, (d & 15) + 16 * g) + e] = val[j];
+        }
+    }
+}
+// Transposed fragment (db, ks) for this lane, either from the t image or gathered from the row image.
+template <typename T, typename C>
+__device__ __forceinline__ typename Elem<T>::v8 load_tfrag(const T* timg, const T* rimg, int db, int ks, int lane) {
+    typedef typename Elem<T>::v8 v8;
+    if constexpr (C::TIMG) {
+        return *(const v8*)(timg + tf_idx<C>(db, ks, lane));
+    } else {
+        const int x = lane & 15, g = lane >> 4;
+        const int d = db * 16 + x;
+        const int dc = d >> 5, gg = (d & 31) >> 3, ee = d & 7;
+        v8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int sb = 2 * ks + (e >> 2), xs = g * 4 + (e & 3);
+            r[e] = rimg[rf_idx<C>(sb, dc, xs + 16 * gg) + ee];
+        }
+        return r;
+    }
+}
+
+template <typename T, typename C>
+__device__ __forceinline__ typename Elem<T>::v8 load_qfrag(const T* base, int t, int T_, size_t row_stride, int dcol) {
+    typedef typename Elem<T>::v8 v8;
+    if (t < T_ && dcol < C::D) return *(const v8*)(base + (size_t)t * row_stride + dcol);
+    return vzero<v8>();
+}
+
+template <typename T> __device__ __forceinline__ void store4(T* p, const f32x4& v);
+template <> __device__ __forceinline__ void store4<float>(float* p, const f32x4& v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const f32x4& v) {
+    *(bf16x4*)p = __builtin_convertvector(v, bf16x4);
+}
+
+// per-lane validity bits of the keys this lane owns in accumulator layout: bit (4 sb + r) <-> s = 16 sb + 4 g + r
+template <typename C> __device__ __forceinline__ void lane_key_bits(const uint8_t* vld, int g, int S, uint32_t& vbits_lo,
+                                                                    uint32_t& vbits_hi, uint32_t& ebits_lo, uint32_t& ebits_hi) {
+    uint64_t vb = 0, eb = 0;
+#pragma unroll
+    for (int sb = 0; sb < C::NSB; ++sb) {
+        const uint32_t w = *(const uint32_t*)(vld + sb * 16 + g * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if ((w >> (8 * r)) & 0xffu) vb |= (1ull << (sb * 4 + r));
+            if (sb * 16 + g * 4 + r < S) eb |= (1ull << (sb * 4 + r));
+        }
+    }
+    vbits_lo = (uint32_t)vb; vbits_hi = (uint32_t)(vb >> 32);
+    ebits_lo = (uint32_t)eb; ebits_hi = (uint32_t)(eb >> 32);
+}
+__device__ __forceinline__ bool bit64(uint32_t lo, uint32_t hi, int i) {
+    return i < 32 ? ((lo >> i) & 1u) : ((hi >> (i - 32)) & 1u);
+}
+
+// ============================================================================================ forward
+template <typename T, int D, int NSB>
+__global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                        const T* __restrict__ v, const uint8_t* __restrict__ valid,
+                                                        T* __restrict__ out, float* __restrict__ lse, int B, int H,
+                                                        int T_, int S, int rows_per_wave, int nchunk) {
+    typedef XC<T, D, NSB> C;
+    typedef typename Elem<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Kf = (T*)smem;
+    T* Vt = Kf + C::ROWIMG;                                   // t image (bf16) or row image (f32)
+    uint8_t* vld = (uint8_t*)(Vt + (C::TIMG ? C::TIMGSZ : C::ROWIMG));
+
+    const int vid = xcd_remap(blockIdx.x, B * H * nchunk);
+    const int bh = vid / nchunk, chunk = vid % nchunk;
+    const int b = bh / H, h = bh % H;
+    const size_t HD = (size_t)H * D;
+
+    stage_row_image<T, C>(Kf, k + (size_t)b * S * HD + h * D, HD, S);
+    if constexpr (C::TIMG) stage_t_image<T, C>(Vt, v + (size_t)b * S * HD + h * D, HD, S);
+    else stage_row_image<T, C>(Vt, v + (size_t)b * S * HD + h * D, HD, S);
+    for (int i = threadIdx.x; i < C::SPAD; i += blockDim.x) vld[i] = (i < S) ? valid[(size_t)b * S + i] : 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = lane & 15, g = lane >> 4;
+    uint32_t vlo, vhi, elo, ehi;
+    lane_key_bits<C>(vld, g, S, vlo, vhi, elo, ehi);
+    const bool any_valid = __ballot((vlo | vhi) != 0) != 0ull;
+
+    const int row_begin = chunk * 4 * rows_per_wave + wave * rows_per_wave;
+    const int row_end = min(row_begin + rows_per_wave, T_);
+    const T* qb = q + (size_t)b * T_ * HD + h * D;
+    T* ob = out + (size_t)b * T_ * HD + h * D;
+    float* lb = lse + (size_t)bh * T_;
+
+    for (int t0 = row_begin; t0 < row_end; t0 += 16 * C::QT) {
+        if constexpr (!C::HOIST) asm volatile("" ::: "memory");
+        v8 qf[C::QT][C::NDC];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc)
+                qf[qt][dc] = load_qfrag<T, C>(qb, t0 + qt * 16 + x, T_, HD, dc * 32 + g * 8);
+
+        f32x4 sacc[C::QT][C::NSB];
+#pragma unroll
+        for (int sb = 0; sb < C::NSB; ++sb) {
+#pragma unroll
+            for (int qt = 0; qt < C::QT; ++qt) sacc[qt][sb] = vzero<f32x4>();
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc) {
+                const v8 kf = *(const v8*)(Kf + rf_idx<C>(sb, dc, lane));
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt) mma16(sacc[qt][sb], kf, qf[qt][dc]);
+            }
+        }
+
+        v8 pf[C::QT][C::NKS];
+        float linv[C::QT], lsev[C::QT];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            float m = -INFINITY, l = 0.f;
+            if (any_valid) {
+#pragma unroll
+                for (int sb = 0; sb < C::NSB; ++sb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (bit64(vlo, vhi, sb * 4 + r)) m = fmaxf(m, sacc[qt][sb][r]);
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+#pragma unroll
+                for (int sb = 0; sb < C::NSB; ++sb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = bit64(vlo, vhi, sb * 4 + r) ? __expf(sacc[qt][sb][r] - m) : 0.f;
+                        sacc[qt][sb][r] = p;
+                        l += p;
+                    }
+            } else {   // every key masked: all scores clamp to finfo.min -> uniform over the S real keys
+                m = 0.f;
+#pragma unroll
+                for (int sb = 0; sb < C::NSB; ++sb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = bit64(elo, ehi, sb * 4 + r) ? 1.f : 0.f;
+                        sacc[qt][sb][r] = p;
+                        l += p;
+                    }
+            }
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            linv[qt] = 1.f / l;
+            lsev[qt] = m + __logf(l);
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks) pf[qt][ks] = pack8<T>(sacc[qt][2 * ks], sacc[qt][2 * ks + 1]);
+        }
+
+        f32x4 oacc[C::QT][C::NDB];
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) {
+#pragma unroll
+            for (int qt = 0; qt < C::QT; ++qt) oacc[qt][db] = vzero<f32x4>();
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks) {
+                const v8 vt = load_tfrag<T, C>(Vt, Vt, db, ks, lane);
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt) mma16(oacc[qt][db], vt, pf[qt][ks]);
+            }
+        }
+
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            const int t = t0 + qt * 16 + x;
+            if (t < T_) {
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) store4<T>(ob + (size_t)t * HD + db * 16 + g * 4, oacc[qt][db] * linv[qt]);
+                if (g == 0) lb[t] = lsev[qt];
+            }
+        }
+    }
+}
+
+// ============================================================================================ backward 1: dQ (+ row dots)
+// Same streaming structure as forward.  P is recomputed from the saved LSE; delta_t = sum_s P dP (== dO.O, so O is
+// never re-read); dS = P (dP - delta); dQ^T = K^T dS^T.  delta is written for the dK/dV kernel.
+template <typename T, int D, int NSB>
+__global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const T* __restrict__ dout, const T* __restrict__ q,
+                                                           const T* __restrict__ k, const T* __restrict__ v,
+                                                           const float* __restrict__ lse, const uint8_t* __restrict__ valid,
+                                                           T* __restrict__ dq, float* __restrict__ delta, int B, int H,
+                                                           int T_, int S, int rows_per_wave, int nchunk) {
+    typedef XC<T, D, NSB, 2> C;
+    typedef typename Elem<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Kf = (T*)smem;
+    T* Vf = Kf + C::ROWIMG;
+    T* Kt = Vf + C::ROWIMG;                                   // only when TIMG
+    uint8_t* vld = (uint8_t*)(Kt + (C::TIMG ? C::TIMGSZ : 0));
+
+    const int vid = xcd_remap(blockIdx.x, B * H * nchunk);
+    const int bh = vid / nchunk, chunk = vid % nchunk;
+    const int b = bh / H, h = bh % H;
+    const size_t HD = (size_t)H * D;
+
+    stage_row_image<T, C>(Kf, k + (size_t)b * S * HD + h * D, HD, S);
+    stage_row_image<T, C>(Vf, v + (size_t)b * S * HD + h * D, HD, S);
+    if constexpr (C::TIMG) stage_t_image<T, C>(Kt, k + (size_t)b * S * HD + h * D, HD, S);
+    for (int i = threadIdx.x; i < C::SPAD; i += blockDim.x) vld[i] = (i < S) ? valid[(size_t)b * S + i] : 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = lane & 15, g = lane >> 4;
+    uint32_t vlo, vhi, elo, ehi;
+    lane_key_bits<C>(vld, g, S, vlo, vhi, elo, ehi);
+    const bool any_valid = __ballot((vlo | vhi) != 0) != 0ull;
+    const float uni = 1.f / (float)S;
+    const float tie = any_valid ? 1.f : 0.5f;                 // autograd's 50/50 split at the torch.max tie
+
+    const int row_begin = chunk * 4 * rows_per_wave + wave * rows_per_wave;
+    const int row_end = min(row_begin + rows_per_wave, T_);
+    const T* qb = q + (size_t)b * T_ * HD + h * D;
+    const T* gb = dout + (size_t)b * T_ * HD + h * D;
+    T* dqb = dq + (size_t)b * T_ * HD + h * D;
+    const float* lb = lse + (size_t)bh * T_;
+    float* db_ = delta + (size_t)bh * T_;
+
+    for (int t0 = row_begin; t0 < row_end; t0 += 16 * C::QT) {
+        if constexpr (!C::HOIST) asm volatile("" ::: "memory");
+        v8 qf[C::QT][C::NDC], gf[C::QT][C::NDC];
+        float lset[C::QT];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            const int t = t0 + qt * 16 + x;
+            lset[qt] = (t < T_) ? lb[t] : 0.f;
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc) {
+                qf[qt][dc] = load_qfrag<T, C>(qb, t, T_, HD, dc * 32 + g * 8);
+                gf[qt][dc] = load_qfrag<T, C>(gb, t, T_, HD, dc * 32 + g * 8);
+            }
+        }
+        v8 dsf[C::QT][C::NKS];
+        float dlt[C::QT];
+        {
+            f32x4 sacc[C::QT][C::NSB], pacc[C::QT][C::NSB];
+#pragma unroll
+            for (int sb = 0; sb < C::NSB; ++sb) {
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt) { sacc[qt][sb] = vzero<f32x4>(); pacc[qt][sb] = vzero<f32x4>(); }
+#pragma unroll
+                for (int dc = 0; dc < C::NDC; ++dc) {
+                    const v8 kf = *(const v8*)(Kf + rf_idx<C>(sb, dc, lane));
+                    const v8 vf = *(const v8*)(Vf + rf_idx<C>(sb, dc, lane));
+#pragma unroll
+                    for (int qt = 0; qt < C::QT; ++qt) {
+                        mma16(sacc[qt][sb], kf, qf[qt][dc]);
+                        mma16(pacc[qt][sb], vf, gf[qt][dc]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int qt = 0; qt < C::QT; ++qt) {
+                float dl = 0.f;
+#pragma unroll
+                for (int sb = 0; sb < C::NSB; ++sb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p;
+                        if (any_valid) p = bit64(vlo, vhi, sb * 4 + r) ? __expf(sacc[qt][sb][r] - lset[qt]) : 0.f;
+                        else p = bit64(elo, ehi, sb * 4 + r) ? uni : 0.f;
+                        sacc[qt][sb][r] = p;
+                        dl += p * pacc[qt][sb][r];
+                    }
+                dl += __shfl_xor(dl, 16);
+                dl += __shfl_xor(dl, 32);
+                dlt[qt] = dl;
+#pragma unroll
+                for (int sb = 0; sb < C::NSB; ++sb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[qt][sb][r] = tie * sacc[qt][sb][r] * (pacc[qt][sb][r] - dl);
+#pragma unroll
+                for (int ks = 0; ks < C::NKS; ++ks) dsf[qt][ks] = pack8<T>(sacc[qt][2 * ks], sacc[qt][2 * ks + 1]);
+            }
+        }
+        f32x4 acc[C::QT][C::NDB];
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) {
+#pragma unroll
+            for (int qt = 0; qt < C::QT; ++qt) acc[qt][db] = vzero<f32x4>();
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks) {
+                const v8 kt = load_tfrag<T, C>(Kt, Kf, db, ks, lane);
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt) mma16(acc[qt][db], kt, dsf[qt][ks]);
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            const int t = t0 + qt * 16 + x;
+            if (t < T_) {
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) store4<T>(dqb + (size_t)t * HD + db * 16 + g * 4, acc[qt][db]);
+                if (g == 0) db_[t] = dlt[qt];
+            }
+        }
+    }
+}
+
+// ============================================================================================ backward 2: dK, dV partials
+// One wave per (batch, head, 32-key group, T-chunk).  Non-swapped products put lane = key column, so the
+// probabilities come out of the S = Q K^T accumulator directly in B-operand layout for the contraction over t:
+//     dV^T[d][s] += dO^T[d][t] P[t][s]      dK^T[d][s] += Q^T[d][t] dS[t][s]
+// No row reductions are needed here: LSE comes from forward, delta from the dQ kernel.  The transposed Q / dO
+// operands are read back from a wave-private row-major LDS tile.
+template <typename T, int D>
+__global__ __launch_bounds__(64) void xattn_bwd_dkv_kernel(const T* __restrict__ dout, const T* __restrict__ q,
+                                                           const T* __restrict__ k, const T* __restrict__ v,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           const uint8_t* __restrict__ valid, float* __restrict__ dk_part,
+                                                           float* __restrict__ dv_part, int B, int H, int T_, int S,
+                                                           int nsg, int rows_per_chunk, int nchunk) {
+    typedef XC<T, D, 2> C;                       // one 32-key group = 2 key blocks
+    typedef typename Elem<T>::v8 v8;
+    constexpr int DLD = C::DPAD + (sizeof(T) == 2 ? 8 : 4);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Kb = (T*)smem;
+    T* Vb = Kb + C::ROWIMG;
+    T* Qt = Vb + C::ROWIMG;
+    T* Gt = Qt + 32 * DLD;
+
+    const int vid = xcd_remap(blockIdx.x, B * H * nsg * nchunk);
+    const int chunk = vid % nchunk;
+    const int sg = (vid / nchunk) % nsg;
+    const int bh = vid / (nchunk * nsg);
+    const int b = bh / H, h = bh % H;
+    const size_t HD = (size_t)H * D;
+    const int s0 = sg * 32;
+
+    stage_row_image<T, C>(Kb, k + ((size_t)b * S + s0) * HD + h * D, HD, S - s0);
+    stage_row_image<T, C>(Vb, v + ((size_t)b * S + s0) * HD + h * D, HD, S - s0);
+
+    const int lane = threadIdx.x, x = lane & 15, g = lane >> 4;
+    bool any = false;
+    for (int s = lane; s < S; s += 64) any |= valid[(size_t)b * S + s] != 0;
+    const bool any_valid = __ballot(any) != 0ull;
+    const float uni = 1.f / (float)S, tie = any_valid ? 1.f : 0.5f;
+    bool vs[2], es[2];
+#pragma unroll
+    for (int sbl = 0; sbl < 2; ++sbl) {
+        const int s = s0 + sbl * 16 + x;
+        es[sbl] = s < S;
+        vs[sbl] = es[sbl] && valid[(size_t)b * S + s] != 0;
+    }
+    __syncthreads();
+
+    f32x4 dva[C::NDB][2], dka[C::NDB][2];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int sbl = 0; sbl < 2; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
+
+    const T* qb = q + (size_t)b * T_ * HD + h * D;
+    const T* gb = dout + (size_t)b * T_ * HD + h * D;
+    const float* lb = lse + (size_t)bh * T_;
+    const float* dlb = delta + (size_t)bh * T_;
+    const int row_begin = chunk * rows_per_chunk, row_end = min(row_begin + rows_per_chunk, T_);
+
+    for (int t0 = row_begin; t0 < row_end; t0 += 32) {
+        v8 qa[2][C::NDC], ga[2][C::NDC];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc) {
+                const int t = t0 + tb * 16 + x;
+                qa[tb][dc] = load_qfrag<T, C>(qb, t, T_, HD, dc * 32 + g * 8);
+                ga[tb][dc] = load_qfrag<T, C>(gb, t, T_, HD, dc * 32 + g * 8);
+                *(v8*)(Qt + (tb * 16 + x) * DLD + dc * 32 + g * 8) = qa[tb][dc];
+                *(v8*)(Gt + (tb * 16 + x) * DLD + dc * 32 + g * 8) = ga[tb][dc];
+            }
+        f32x4 pr[2][2], dsr[2][2];               // [tb][sbl]
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            float lt[4], dt[4];
+            bool tv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + tb * 16 + g * 4 + r;
+                tv[r] = t < row_end;
+                lt[r] = tv[r] ? lb[t] : 0.f;
+                dt[r] = tv[r] ? dlb[t] : 0.f;
+            }
+#pragma unroll
+            for (int sbl = 0; sbl < 2; ++sbl) {
+                f32x4 sa = vzero<f32x4>(), pa = vzero<f32x4>();
+#pragma unroll
+                for (int dc = 0; dc < C::NDC; ++dc) {
+                    const v8 kb = *(const v8*)(Kb + rf_idx<C>(sbl, dc, lane));
+                    const v8 vb = *(const v8*)(Vb + rf_idx<C>(sbl, dc, lane));
+                    mma16(sa, qa[tb][dc], kb);
+                    mma16(pa, ga[tb][dc], vb);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p;
+                    if (any_valid) p = (tv[r] && vs[sbl]) ? __expf(sa[r] - lt[r]) : 0.f;
+                    else p = (tv[r] && es[sbl]) ? uni : 0.f;
+                    pr[tb][sbl][r] = p;
+                    dsr[tb][sbl][r] = tie * p * (pa[r] - dt[r]);
+                }
+            }
+        }
+        v8 pB[2], dsB[2];
+#pragma unroll
+        for (int sbl = 0; sbl < 2; ++sbl) {
+            pB[sbl] = pack8<T>(pr[0][sbl], pr[1][sbl]);
+            dsB[sbl] = pack8<T>(dsr[0][sbl], dsr[1][sbl]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) {
+            v8 gT, qT;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int row = (e >> 2) * 16 + g * 4 + (e & 3);
+                gT[e] = Gt[row * DLD + db * 16 + x];
+                qT[e] = Qt[row * DLD + db * 16 + x];
+            }
+#pragma unroll
+            for (int sbl = 0; sbl < 2; ++sbl) {
+                mma16(dva[db][sbl], gT, pB[sbl]);
+                mma16(dka[db][sbl], qT, dsB[sbl]);
+            }
+        }
+        __syncthreads();
+    }
+    // partials [nchunk][B][S][H*D] fp32; lane (x = key, g) owns channels 16 db + 4 g .. +3
+#pragma unroll
+    for (int sbl = 0; sbl < 2; ++sbl) {
+        const int s = s0 + sbl * 16 + x;
+        if (s < S) {
+            const size_t off = (((size_t)chunk * B + b) * S + s) * HD + h * D + g * 4;
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db) {
+                *(f32x4*)(dk_part + off + db * 16) = dka[db][sbl];
+                *(f32x4*)(dv_part + off + db * 16) = dva[db][sbl];
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, T* __restrict__ outp,
+                                                              size_t n4, size_t chunk_stride4, int nchunk) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 a = ((const f32x4*)part)[i];
+        for (int c = 1; c < nchunk; ++c) a += ((const f32x4*)part)[i + c * chunk_stride4];
+        store4<T>(outp + i * 4, a);
+    }
+}
+
+// ============================================================================================ host dispatch
+struct BwdPlan { int nsg, nchunk, rows_per_chunk; size_t delta_off, dk_off, dv_off, total; };
+
+BwdPlan bwd_plan(int B, int H, int T, int S, int D) {
+    BwdPlan p;
+    p.nsg = (S + 31) / 32;
+    long units = (long)B * H * p.nsg;
+    int nchunk = (int)((2048 + units - 1) / units);
+    int maxchunk = (T + 63) / 64;
+    if (nchunk > maxchunk) nchunk = maxchunk;
+    if (nchunk < 1) nchunk = 1;
+    p.rows_per_chunk = ((T + nchunk - 1) / nchunk + 31) / 32 * 32;
+    p.nchunk = (T + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    size_t hd = (size_t)H * D;
+    p.delta_off = 0;
+    p.dk_off = align_up((size_t)B * H * T * sizeof(float), 256);
+    p.dv_off = p.dk_off + align_up((size_t)p.nchunk * B * S * hd * sizeof(float), 256);
+    p.total = p.dv_off + align_up((size_t)p.nchunk * B * S * hd * sizeof(float), 256);
+    return p;
+}
+
+void fwd_geometry(int B, int H, int T, int qt_rows, int& rows_per_wave, int& nchunk) {
+    // aim for >= ~1024 workgroups (4 per CU) while keeping >= one iteration per wave
+    int bh = B * H;
+    int want = (1024 + bh - 1) / bh;
+    int rpw = (T + 4 * want - 1) / (4 * want);
+    rpw = (rpw + qt_rows - 1) / qt_rows * qt_rows;
+    if (rpw < qt_rows) rpw = qt_rows;
+    rows_per_wave = rpw;
+    nchunk = (T + 4 * rpw - 1) / (4 * rpw);
+}
+
+template <typename K> int set_lds(K kern, size_t bytes) {
+    if (bytes > 160 * 1024) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "xattn: S*D needs %zu B of LDS (> 160 KiB)", bytes);
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    return MMGL_OK;
+}
+
+template <typename T, int D, int NSB>
+int launch_fwd(const void* q, const void* k, const void* v, const uint8_t* valid, void* out, float* lse, int B, int H,
+               int T_, int S, hipStream_t st) {
+    typedef XC<T, D, NSB> C;
+    int rpw, nchunk;
+    fwd_geometry(B, H, T_, 16 * C::QT, rpw, nchunk);
+    size_t lds = sizeof(T) * (C::ROWIMG + (C::TIMG ? C::TIMGSZ : C::ROWIMG)) + C::SPAD;
+    auto kern = xattn_fwd_kernel<T, D, NSB>;
+    int rc = set_lds(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(B * H * nchunk), dim3(256), lds, st, (const T*)q, (const T*)k, (const T*)v, valid,
+                       (T*)out, lse, B, H, T_, S, rpw, nchunk);
+    MMGL_CHECK_LAUNCH("xattn_fwd");
+    return MMGL_OK;
+}
+
+template <typename T, int D, int NSB>
+int launch_bwd(const void* dout, const void* q, const void* k, const void* v, const float* lse, const uint8_t* valid,
+               void* dq, void* dk, void* dv, char* ws, int B, int H, int T_, int S, hipStream_t st) {
+    typedef XC<T, D, NSB, 2> C;
+    const BwdPlan p = bwd_plan(B, H, T_, S, D);
+    float* delta = (float*)(ws + p.delta_off);
+    float* dkp = (float*)(ws + p.dk_off);
+    float* dvp = (float*)(ws + p.dv_off);
+    {
+        int rpw, nchunk;
+        fwd_geometry(B, H, T_, 16 * C::QT, rpw, nchunk);
+        size_t lds = sizeof(T) * (2 * C::ROWIMG + (C::TIMG ? C::TIMGSZ : 0)) + C::SPAD;
+        auto kern = xattn_bwd_dq_kernel<T, D, NSB>;
+        int rc = set_lds(kern, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(B * H * nchunk), dim3(256), lds, st, (const T*)dout, (const T*)q, (const T*)k,
+                           (const T*)v, lse, valid, (T*)dq, delta, B, H, T_, S, rpw, nchunk);
+        MMGL_CHECK_LAUNCH("xattn_bwd_dq");
+    }
+    {
+        typedef XC<T, D, 2> C2;
+        constexpr int DLD = C2::DPAD + (sizeof(T) == 2 ? 8 : 4);
+        size_t lds = sizeof(T) * (2 * C2::ROWIMG + 2 * 32 * DLD);
+        auto kern = xattn_bwd_dkv_kernel<T, D>;
+        int rc = set_lds(kern, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(B * H * p.nsg * p.nchunk), dim3(64), lds, st, (const T*)dout, (const T*)q,
+                           (const T*)k, (const T*)v, lse, delta, valid, dkp, dvp, B, H, T_, S, p.nsg, p.rows_per_chunk,
+                           p.nchunk);
+        MMGL_CHECK_LAUNCH("xattn_bwd_dkv");
+    }
+    {
+        size_t n4 = (size_t)B * S * H * D / 4;
+        int blocks = (int)((n4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3(blocks), dim3(256), 0, st, dkp, (T*)dk, n4, n4, p.nchunk);
+        hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3(blocks), dim3(256), 0, st, dvp, (T*)dv, n4, n4, p.nchunk);
+        MMGL_CHECK_LAUNCH("xattn_bwd_reduce");
+    }
+    return MMGL_OK;
+}
+
+int check_shape(const char* who, int B, int H, int T, int S, int D, int dtype) {
+    MMGL_CHECK_ARG(B > 0 && H > 0 && T > 0 && S > 0, "%s: B,H,T,S must be positive (got %d,%d,%d,%d)", who, B, H, T, S);
+    MMGL_CHECK_ARG(dtype == MMGL_F32 || dtype == MMGL_BF16, "%s: dtype must be MMGL_F32 or MMGL_BF16", who);
+    if (!(D == 16 || D == 32 || D == 64 || D == 128))
+        MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "%s: head_dim %d not in {16,32,64,128}", who, D);
+    if (S > 256) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "%s: %d neighbor key tokens > 256 (single-pass kernel)", who, S);
+    return MMGL_OK;
+}
+
+#define DISPATCH_NSB(FN, T, D, ...)                                    \
+    do {                                                               \
+        if (S <= 32) return FN<T, D, 2>(__VA_ARGS__);                  \
+        if (S <= 64) return FN<T, D, 4>(__VA_ARGS__);                  \
+        if (S <= 128) return FN<T, D, 8>(__VA_ARGS__);                 \
+        return FN<T, D, 16>(__VA_ARGS__);                              \
+    } while (0)
+#define DISPATCH_D(FN, T, ...)                                         \
+    do {                                                               \
+        switch (D) {                                                   \
+            case 16: DISPATCH_NSB(FN, T, 16, __VA_ARGS__);             \
+            case 32: DISPATCH_NSB(FN, T, 32, __VA_ARGS__);             \
+            case 64: DISPATCH_NSB(FN, T, 64, __VA_ARGS__);             \
+            default: DISPATCH_NSB(FN, T, 128, __VA_ARGS__);            \
+        }                                                              \
+    } while (0)
+
+}  // namespace
+
+extern "C" int mmgl_xattn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out,
+                              float* lse, int B, int H, int T, int S, int D, float p_drop, uint64_t seed,
+                              uint64_t offset, int dtype, void* stream) {
+    (void)seed; (void)offset;
+    int rc = check_shape("mmgl_xattn_fwd", B, H, T, S, D, dtype);
+    if (rc) return rc;
+    MMGL_CHECK_ARG(q && k && v && key_valid && out && lse, "mmgl_xattn_fwd: null pointer");
+    if (p_drop != 0.f) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "mmgl_xattn_fwd: attention dropout %g != 0 is not implemented", p_drop);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMGL_BF16) DISPATCH_D(launch_fwd, bf16, q, k, v, key_valid, out, lse, B, H, T, S, st);
+    DISPATCH_D(launch_fwd, float, q, k, v, key_valid, out, lse, B, H, T, S, st);
+}
+
+extern "C" size_t mmgl_xattn_bwd_workspace(int B, int H, int T, int S, int D) {
+    if (B <= 0 || H <= 0 || T <= 0 || S <= 0 || D <= 0) return 0;
+    return bwd_plan(B, H, T, S, D).total;
+}
+
+extern "C" int mmgl_xattn_bwd(const void* dout, const void* q, const void* k, const void* v, const float* lse,
+                              const uint8_t* key_valid, void* dq, void* dk, void* dv, void* workspace,
+                              size_t workspace_bytes, int B, int H, int T, int S, int D, int dtype, void* stream) {
+    int rc = check_shape("mmgl_xattn_bwd", B, H, T, S, D, dtype);
+    if (rc) return rc;
+    MMGL_CHECK_ARG(dout && q && k && v && lse && key_valid && dq && dk && dv && workspace, "mmgl_xattn_bwd: null pointer");
+    MMGL_CHECK_ARG(workspace_bytes >= bwd_plan(B, H, T, S, D).total, "mmgl_xattn_bwd: workspace %zu B < required %zu B",
+                   workspace_bytes, bwd_plan(B, H, T, S, D).total);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    if (dtype == MMGL_BF16) DISPATCH_D(launch_bwd, bf16, dout, q, k, v, lse, key_valid, dq, dk, dv, ws, B, H, T, S, st);
+    DISPATCH_D(launch_bwd, float, dout, q, k, v, lse, key_valid, dq, dk, dv, ws, B, H, T, S, st);
+}

@@ -1,0 +1,373 @@
+"""torch.autograd.Function wrappers over the C-ABI kernels (one per fwd/bwd pair).
+
+Each op validates shapes the way the reference does (ValueError), makes inputs contiguous, calls the HIP
+entry point on torch's current stream and returns fresh tensors owned by autograd.  GPU only.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check, dtype_code, lib, ptr, require_cuda, stream_ptr
+
+
+# ------------------------------------------------------------------------------------------ attention core
+class _XAttnCore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, key_valid, num_heads):
+        require_cuda(q, k, v, key_valid)
+        B, T, d = q.shape
+        S = k.shape[1]
+        D = d // num_heads
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out = torch.empty_like(q)
+        lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=q.device)
+        check(lib().mmgl_xattn_fwd(ptr(q), ptr(k), ptr(v), ptr(key_valid), ptr(out), ptr(lse), B, num_heads, T, S, D,
+                                   0.0, 0, 0, dtype_code(q), stream_ptr()), "mmgl_xattn_fwd")
+        ctx.save_for_backward(q, k, v, key_valid, lse)
+        ctx.num_heads = num_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, key_valid, lse = ctx.saved_tensors
+        H = ctx.num_heads
+        B, T, d = q.shape
+        S = k.shape[1]
+        D = d // H
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        nbytes = lib().mmgl_xattn_bwd_workspace(B, H, T, S, D)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        check(lib().mmgl_xattn_bwd(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(lse), ptr(key_valid), ptr(dq), ptr(dk), ptr(dv),
+                                   ptr(ws), nbytes, B, H, T, S, D, dtype_code(q), stream_ptr()), "mmgl_xattn_bwd")
+        return dq, dk, dv, None, None
+
+
+def xattn_core(q, k, v, key_valid, num_heads):
+    """softmax(max(q k^T + M, finfo.min)) v per head.  q [B,T,d] is already scaled; k, v [B,S,d];
+    key_valid [B,S] bool/uint8 (True = attend).  Mirrors the core of MPTAttention.forward
+    (reference model/modelling_cross_attention.py:206-271)."""
+    if q.dim() != 3 or k.shape != v.shape or k.dim() != 3 or q.shape[0] != k.shape[0] or q.shape[2] != k.shape[2]:
+        raise ValueError(f"xattn_core: incompatible shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+    if q.shape[2] % num_heads:
+        raise ValueError(f"embed_dim must be divisible by num_heads (got `embed_dim`: {q.shape[2]} and `num_heads`: {num_heads}).")
+    if key_valid.shape != k.shape[:2]:
+        raise ValueError(f"Attention mask should be of size {tuple(k.shape[:2])}, but is {tuple(key_valid.shape)}")
+    if key_valid.dtype != torch.uint8:
+        key_valid = key_valid.to(torch.uint8)
+    return _XAttnCore.apply(q, k, v, key_valid.contiguous(), num_heads)
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm / RMSNorm
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        require_cuda(x)
+        shape = x.shape
+        cols = shape[-1]
+        x2 = x.contiguous().view(-1, cols)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        g = None if gamma is None else gamma.to(x.dtype).contiguous()
+        b = None if beta is None else beta.to(x.dtype).contiguous()
+        check(lib().mmgl_layernorm_fwd(ptr(x2), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps,
+                                       dtype_code(x), stream_ptr()), "mmgl_layernorm_fwd")
+        ctx.save_for_backward(x2, g, mean, rstd)
+        ctx.shape = shape
+        ctx.pgrad = (gamma is not None and gamma.requires_grad, beta is not None and beta.requires_grad)
+        ctx.pdtype = None if gamma is None else gamma.dtype
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, mean, rstd = ctx.saved_tensors
+        rows, cols = x2.shape
+        dy2 = dy.contiguous().view(rows, cols)
+        dx = torch.empty_like(x2)
+        want = any(ctx.pgrad)
+        dgamma = torch.empty(cols, dtype=torch.float32, device=x2.device) if want else None
+        dbeta = torch.empty(cols, dtype=torch.float32, device=x2.device) if want else None
+        nbytes = lib().mmgl_norm_bwd_workspace(rows, cols) if want else 0
+        ws = _ws(nbytes, x2.device)
+        check(lib().mmgl_layernorm_bwd(ptr(dy2), ptr(x2), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
+                                       ptr(ws), ws.numel(), rows, cols, dtype_code(x2), stream_ptr()), "mmgl_layernorm_bwd")
+        dg = dgamma.to(ctx.pdtype) if ctx.pgrad[0] else None
+        db = dbeta.to(ctx.pdtype) if ctx.pgrad[1] else None
+        return dx.view(ctx.shape), dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    """nn.LayerNorm over the last dim (reference model/modelling_cross_attention.py:287-294, 319-320, 349-350)."""
+    return _LayerNorm.apply(x, gamma, beta, float(eps))
+
+
+class _RMSNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, eps):
+        require_cuda(x)
+        shape = x.shape
+        cols = shape[-1]
+        x2 = x.contiguous().view(-1, cols)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        g = None if gamma is None else gamma.to(x.dtype).contiguous()
+        check(lib().mmgl_rmsnorm_fwd(ptr(x2), ptr(g), ptr(y), ptr(rstd), rows, cols, eps, dtype_code(x), stream_ptr()),
+              "mmgl_rmsnorm_fwd")
+        ctx.save_for_backward(x2, g, rstd)
+        ctx.shape = shape
+        ctx.pgrad = gamma is not None and gamma.requires_grad
+        ctx.pdtype = None if gamma is None else gamma.dtype
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, rstd = ctx.saved_tensors
+        rows, cols = x2.shape
+        dy2 = dy.contiguous().view(rows, cols)
+        dx = torch.empty_like(x2)
+        dgamma = torch.empty(cols, dtype=torch.float32, device=x2.device) if ctx.pgrad else None
+        nbytes = lib().mmgl_norm_bwd_workspace(rows, cols) if ctx.pgrad else 0
+        ws = _ws(nbytes, x2.device)
+        check(lib().mmgl_rmsnorm_bwd(ptr(dy2), ptr(x2), ptr(g), ptr(rstd), ptr(dx), ptr(dgamma), ptr(ws), ws.numel(), rows,
+                                     cols, dtype_code(x2), stream_ptr()), "mmgl_rmsnorm_bwd")
+        return dx.view(ctx.shape), (dgamma.to(ctx.pdtype) if ctx.pgrad else None), None
+
+
+def rms_norm(x, gamma, eps=1e-6):
+    return _RMSNorm.apply(x, gamma, float(eps))
+
+
+# ------------------------------------------------------------------------------------------ gated residual
+class _GatedResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, residual, x, gate, p_drop, seed):
+        require_cuda(residual, x)
+        residual, x = residual.contiguous(), x.contiguous()
+        y = torch.empty_like(x)
+        g32 = None if gate is None else gate.detach().to(torch.float32).reshape(1).contiguous()
+        check(lib().mmgl_gated_residual_fwd(ptr(residual), ptr(x), ptr(g32), ptr(y), x.numel(), p_drop, seed,
+                                            dtype_code(x), stream_ptr()), "mmgl_gated_residual_fwd")
+        ctx.save_for_backward(x, g32)
+        ctx.p, ctx.seed = p_drop, seed
+        ctx.gate_meta = None if gate is None else (gate.dtype, gate.shape, gate.requires_grad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g32 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgate = torch.zeros(1, dtype=torch.float32, device=x.device) if g32 is not None else None
+        ws = _ws(lib().mmgl_gated_residual_bwd_workspace(x.numel()), x.device)
+        check(lib().mmgl_gated_residual_bwd(ptr(dy), ptr(x), ptr(g32), ptr(dx), ptr(dgate), ptr(ws), ws.numel(), x.numel(),
+                                            ctx.p, ctx.seed, dtype_code(x), stream_ptr()), "mmgl_gated_residual_bwd")
+        dg = None
+        if ctx.gate_meta is not None and ctx.gate_meta[2]:
+            dg = dgate.to(ctx.gate_meta[0]).reshape(ctx.gate_meta[1])
+        return dy, dx, dg, None, None
+
+
+def gated_residual(residual, x, gate=None, p_drop=0.0, training=False, seed=None):
+    """residual + tanh(gate) * dropout(x)  (reference :332-335, :356-359; gate=None is the ungated :337/:361 form).
+    The dropout mask is a counter hash of (seed, index) regenerated in backward."""
+    p = float(p_drop) if training else 0.0
+    if p > 0.0 and seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return _GatedResidual.apply(residual, x, gate, p, int(seed or 0))
+
+
+# ------------------------------------------------------------------------------------------ linear (+bias, scale, ReLU)
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, out_scale):
+        require_cuda(x, weight)
+        shape = x.shape
+        K = shape[-1]
+        N = weight.shape[0]
+        x2 = x.contiguous().view(-1, K)
+        M = x2.shape[0]
+        w = weight.to(x.dtype).contiguous()
+        b = None if bias is None else bias.to(x.dtype).contiguous()
+        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        check(lib().mmgl_linear_fwd(ptr(x2), ptr(w), ptr(b), ptr(y), M, N, K, act, out_scale, dtype_code(x), stream_ptr()),
+              "mmgl_linear_fwd")
+        ctx.save_for_backward(x2, w, y if act else None)
+        ctx.meta = (shape, act, out_scale, weight.dtype, None if bias is None else bias.dtype)
+        ctx.need = (x.requires_grad, weight.requires_grad, bias is not None and bias.requires_grad)
+        return y.view(*shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        shape, act, out_scale, wdt, bdt = ctx.meta
+        M, K = x2.shape
+        N = w.shape[0]
+        dy2 = dy.contiguous().view(M, N)
+        code = dtype_code(x2)
+        dx = dw = db = None
+        if ctx.need[0]:
+            dx = torch.empty_like(x2)
+            ws = _ws(lib().mmgl_linear_dgrad_workspace(M, N, K, act, code), x2.device)
+            check(lib().mmgl_linear_dgrad(ptr(dy2), ptr(y), ptr(w), ptr(dx), ptr(ws), ws.numel(), M, N, K, act, out_scale, code,
+                                          stream_ptr()), "mmgl_linear_dgrad")
+            dx = dx.view(shape)
+        if ctx.need[1] or ctx.need[2]:
+            dw = torch.empty_like(w)
+            db = torch.empty(N, dtype=x2.dtype, device=x2.device) if ctx.need[2] else None
+            ws = _ws(lib().mmgl_linear_wgrad_workspace(M, N, K, code), x2.device)
+            check(lib().mmgl_linear_wgrad(ptr(dy2), ptr(y), ptr(x2), ptr(dw), ptr(db), ptr(ws), ws.numel(), M, N, K, act,
+                                          out_scale, 0, code, stream_ptr()), "mmgl_linear_wgrad")
+            dw = dw.to(wdt) if ctx.need[1] else None
+            db = db.to(bdt) if db is not None else None
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias=None, act="none", out_scale=1.0):
+    """act((x @ weight.T + bias) * out_scale); weight is nn.Linear layout [out, in].
+    (reference q/k/v/out_proj :194-199, :273; fc1+ReLU / fc2 :352-355)"""
+    if x.shape[-1] != weight.shape[1]:
+        raise ValueError(f"linear: x has {x.shape[-1]} features, weight expects {weight.shape[1]}")
+    code = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU}.get(act)
+    if code is None:
+        raise ValueError(f"linear: activation {act!r} is not fused (supported: none, relu)")
+    return _Linear.apply(x, weight, bias, code, float(out_scale))
+
+
+class _LoraLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, A, Bm, scale):
+        require_cuda(x, weight, A, Bm)
+        shape = x.shape
+        K = shape[-1]
+        N, r = weight.shape[0], A.shape[0]
+        x2 = x.contiguous().view(-1, K)
+        M = x2.shape[0]
+        w, a, bm = (t.to(x.dtype).contiguous() for t in (weight, A, Bm))
+        b = None if bias is None else bias.to(x.dtype).contiguous()
+        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        xa = torch.empty(M, r, dtype=x.dtype, device=x.device)
+        check(lib().mmgl_lora_linear_fwd(ptr(x2), ptr(w), ptr(b), ptr(a), ptr(bm), ptr(y), ptr(xa), M, N, K, r, scale,
+                                         dtype_code(x), stream_ptr()), "mmgl_lora_linear_fwd")
+        ctx.save_for_backward(x2, xa, w, a, bm)
+        ctx.meta = (shape, scale, A.dtype, Bm.dtype)
+        return y.view(*shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xa, w, a, bm = ctx.saved_tensors
+        shape, scale, adt, bdt = ctx.meta
+        M, K = x2.shape
+        N, r = w.shape[0], a.shape[0]
+        dy2 = dy.contiguous().view(M, N)
+        code = dtype_code(x2)
+        dx, dA, dB = torch.empty_like(x2), torch.empty_like(a), torch.empty_like(bm)
+        dyb = torch.empty(M, r, dtype=x2.dtype, device=x2.device)
+        ws = _ws(lib().mmgl_lora_linear_bwd_workspace(M, N, K, r, code), x2.device)
+        check(lib().mmgl_lora_linear_bwd(ptr(dy2), ptr(x2), ptr(xa), ptr(w), ptr(a), ptr(bm), ptr(dx), ptr(dA), ptr(dB), ptr(dyb),
+                                         ptr(ws), ws.numel(), M, N, K, r, scale, 0, code, stream_ptr()), "mmgl_lora_linear_bwd")
+        return dx.view(shape), None, None, dA.to(adt), dB.to(bdt), None
+
+
+def lora_linear(x, weight, bias, lora_A, lora_B, scale):
+    """x W^T + b + scale * (x A^T) B^T with a frozen base weight (peft LoRA semantics, lora_dropout = 0)."""
+    return _LoraLinear.apply(x, weight, bias, lora_A, lora_B, float(scale))
+
+
+# ------------------------------------------------------------------------------------------ neighbor interleave
+class _Interleave(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, text_emb, vis_emb, text_loc, img_loc, text_pos, img_pos):
+        require_cuda(text_emb)
+        B, Nt, n_tok, d = text_emb.shape
+        Ni = 0 if vis_emb is None else vis_emb.shape[1]
+        text_emb = text_emb.contiguous()
+        vis = None if vis_emb is None else vis_emb.contiguous()
+        out = torch.empty(B, (Nt + Ni) * n_tok, d, dtype=text_emb.dtype, device=text_emb.device)
+        valid = torch.empty(B, (Nt + Ni) * n_tok, dtype=torch.uint8, device=text_emb.device)
+        tl, tp = text_loc.contiguous(), text_pos.contiguous()
+        il = None if img_loc is None else img_loc.contiguous()
+        ip = None if img_pos is None else img_pos.contiguous()
+        check(lib().mmgl_neighbor_interleave_fwd(ptr(text_emb), ptr(vis), ptr(tl), ptr(il), ptr(tp), ptr(ip), ptr(out),
+                                                 ptr(valid), B, Nt, Ni, n_tok, d, dtype_code(text_emb), stream_ptr()),
+              "mmgl_neighbor_interleave_fwd")
+        ctx.save_for_backward(tl, il)
+        ctx.dims = (B, Nt, Ni, n_tok, d)
+        ctx.mark_non_differentiable(valid)
+        return out, valid
+
+    @staticmethod
+    def backward(ctx, dout, _dvalid):
+        tl, il = ctx.saved_tensors
+        B, Nt, Ni, n_tok, d = ctx.dims
+        dout = dout.contiguous()
+        dtext = torch.empty(B, Nt, n_tok, d, dtype=dout.dtype, device=dout.device)
+        dvis = torch.empty(B, Ni, n_tok, d, dtype=dout.dtype, device=dout.device) if Ni else None
+        check(lib().mmgl_neighbor_interleave_bwd(ptr(dout), ptr(tl), ptr(il), ptr(dtext), ptr(dvis), B, Nt, Ni, n_tok, d,
+                                                 dtype_code(dout), stream_ptr()), "mmgl_neighbor_interleave_bwd")
+        return dtext, dvis, None, None, None, None
+
+
+def neighbor_interleave(text_emb, vis_emb, text_loc, img_loc, text_pos, img_pos):
+    """Scatter [B,Nt,n,d] text and [B,Ni,n,d] image neighbor tokens into slot order; returns
+    (neighbor_embeds [B,(Nt+Ni)*n,d], key_valid uint8 [B,(Nt+Ni)*n])   (reference :1080-1104)."""
+    if vis_emb is not None and vis_emb.shape[2:] != text_emb.shape[2:]:
+        raise ValueError("n_text_tokens must equal n_visual_tokens for the interleaved layout (reference :1083-1098)")
+    return _Interleave.apply(text_emb, vis_emb, text_loc, img_loc, text_pos, img_pos)
+
+
+# ------------------------------------------------------------------------------------------ cross entropy
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        require_cuda(logits, labels)
+        rows, V = logits.shape
+        logits = logits.contiguous()
+        labels = labels.contiguous()
+        dev = logits.device
+        row_lse = torch.empty(rows, dtype=torch.float32, device=dev)
+        row_loss = torch.empty(rows, dtype=torch.float32, device=dev)
+        sums = torch.empty(2, dtype=torch.float32, device=dev)
+        check(lib().mmgl_cross_entropy_fwd(ptr(logits), ptr(labels), ptr(row_lse), ptr(row_loss), ptr(sums[0:1]), ptr(sums[1:2]),
+                                           rows, V, ignore_index, dtype_code(logits), stream_ptr()), "mmgl_cross_entropy_fwd")
+        ctx.save_for_backward(logits, labels, row_lse, sums)
+        ctx.ignore = ignore_index
+        return sums[0] / sums[1]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, labels, row_lse, sums = ctx.saved_tensors
+        rows, V = logits.shape
+        dl = dloss.detach().to(torch.float32).reshape(1).contiguous()
+        dlogits = torch.empty_like(logits)
+        check(lib().mmgl_cross_entropy_bwd(ptr(logits), ptr(labels), ptr(row_lse), ptr(sums[1:2]), ptr(dl), ptr(dlogits), rows, V,
+                                           ctx.ignore, dtype_code(logits), stream_ptr()), "mmgl_cross_entropy_bwd")
+        return dlogits, None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    """Mean token cross-entropy of [rows, V] logits (fp32 scalar), nn.CrossEntropyLoss semantics (reference :831-836)."""
+    return _CrossEntropy.apply(logits, labels, int(ignore_index))
+
+
+def position_ids(attention_mask):
+    """cumsum(mask) * mask - 1 + 2  (reference MPTLearnedPositionalEmbedding :135-145)."""
+    require_cuda(attention_mask)
+    m = attention_mask.to(torch.int64).contiguous()
+    out = torch.empty_like(m)
+    check(lib().mmgl_position_ids(ptr(m), ptr(out), m.shape[0], m.shape[1], stream_ptr()), "mmgl_position_ids")
+    return out
+
+
+def adamw_step_(param, master, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """In-place fused AdamW over flat buffers (torch.optim.AdamW formula)."""
+    require_cuda(param, grad)
+    check(lib().mmgl_adamw_step(ptr(param), ptr(master), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, beta1, beta2,
+                                eps, weight_decay, step, grad_scale, dtype_code(param), stream_ptr()), "mmgl_adamw_step")

@@ -1,0 +1,258 @@
+"""-m gpu parity tests for the row / elementwise / GEMM kernels (through the C ABI) against plain fp32 torch on CPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import Fixture, assert_close
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, f32=1e-4, bf=2e-2):
+    return f32 if dtype == torch.float32 else bf
+
+
+def dev(t, dtype):
+    return t.to(dtype).cuda().requires_grad_()
+
+
+@pytest.mark.parametrize("rows,cols", [(37, 64), (640, 768), (2560, 2048), (100, 4096), (9, 1000)])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm(rows, cols, dtype):
+    from mmgl_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g) * 2 + 0.5
+    gamma = torch.randn(cols, generator=g) * 0.2 + 1
+    beta = torch.randn(cols, generator=g) * 0.1
+    w = torch.randn(rows, cols, generator=g)
+    xd, gd, bd = dev(x, dtype), dev(gamma, dtype), dev(beta, dtype)
+    y = ops.layer_norm(xd, gd, bd, 1e-5)
+    (y * w.to(dtype).cuda()).sum().backward()
+    xr, gr, br = (t.detach().float().cpu().requires_grad_() for t in (xd, gd, bd))
+    yr = F.layer_norm(xr, (cols,), gr, br, 1e-5)
+    (yr * w.to(dtype).float()).sum().backward()
+    t = tol(dtype)
+    assert_close(y.float(), yr, t, "y")
+    assert_close(xd.grad.float(), xr.grad, t, "dx")
+    assert_close(gd.grad.float(), gr.grad, t, "dgamma")
+    assert_close(bd.grad.float(), br.grad, t, "dbeta")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_frozen_affine(dtype):
+    from mmgl_amd import ops
+    x = dev(torch.randn(50, 256), dtype)
+    gamma = torch.randn(256).to(dtype).cuda()
+    beta = torch.randn(256).to(dtype).cuda()
+    y = ops.layer_norm(x, gamma, beta)
+    y.sum().backward()
+    xr = x.detach().float().cpu().requires_grad_()
+    F.layer_norm(xr, (256,), gamma.float().cpu(), beta.float().cpu()).sum().backward()
+    assert_close(x.grad.float(), xr.grad, tol(dtype, bf=3e-2), "dx")
+
+
+@pytest.mark.parametrize("rows,cols", [(33, 128), (512, 4096)])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rmsnorm(rows, cols, dtype):
+    from mmgl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(rows, cols, generator=g)
+    gamma = torch.randn(cols, generator=g) * 0.2 + 1
+    w = torch.randn(rows, cols, generator=g)
+    xd, gd = dev(x, dtype), dev(gamma, dtype)
+    y = ops.rms_norm(xd, gd, 1e-6)
+    (y * w.to(dtype).cuda()).sum().backward()
+    xr, gr = (t.detach().float().cpu().requires_grad_() for t in (xd, gd))
+    yr = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6) * gr
+    (yr * w.to(dtype).float()).sum().backward()
+    t = tol(dtype)
+    assert_close(y.float(), yr, t, "y")
+    assert_close(xd.grad.float(), xr.grad, t, "dx")
+    assert_close(gd.grad.float(), gr.grad, t, "dgamma")
+
+
+@pytest.mark.parametrize("n", [(3, 7, 64), (4, 640, 2048), (1, 5, 13)])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gated_residual_eval(n, dtype):
+    from mmgl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    res, x, w = (torch.randn(*n, generator=g) for _ in range(3))
+    gate = torch.tensor(0.7, requires_grad=True)
+    rd, xd = dev(res, dtype), dev(x, dtype)
+    gd = gate.detach().cuda().requires_grad_()
+    y = ops.gated_residual(rd, xd, gd)
+    (y * w.to(dtype).cuda()).sum().backward()
+    rr, xr = (t.detach().float().cpu().requires_grad_() for t in (rd, xd))
+    yr = rr + torch.tanh(gate) * xr
+    (yr * w.to(dtype).float()).sum().backward()
+    t = tol(dtype)
+    assert_close(y.float(), yr, t, "y")
+    assert_close(rd.grad.float(), rr.grad, t, "dres")
+    assert_close(xd.grad.float(), xr.grad, t, "dx")
+    assert_close(gd.grad.float().cpu(), gate.grad, tol(dtype, 1e-4, 2e-2), "dgate")
+    # ungated form
+    y2 = ops.gated_residual(rd, xd, None)
+    assert_close(y2.float(), (rr + xr).detach(), t, "ungated")
+
+
+def test_gated_residual_dropout_consistency():
+    """Training-mode dropout: mask density ~ 1-p, scaling 1/(1-p), and backward regenerates the SAME mask."""
+    from mmgl_amd import ops
+    n, p = 1 << 20, 0.1
+    res = torch.zeros(n, device="cuda")
+    x = torch.ones(n, device="cuda", requires_grad=True)
+    gate = torch.tensor(10.0, device="cuda")     # tanh ~ 1
+    y = ops.gated_residual(res, x, gate, p_drop=p, training=True, seed=1234)
+    kept = (y > 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 5e-3
+    assert_close(y[y > 0].mean(), torch.tensor(1 / (1 - p)), 1e-3, "scale")
+    y.sum().backward()
+    assert torch.equal((x.grad > 0), (y > 0))
+    y2 = ops.gated_residual(res, x.detach(), gate, p_drop=p, training=True, seed=1234)
+    assert torch.equal(y, y2)
+    y3 = ops.gated_residual(res, x.detach(), gate, p_drop=p, training=True, seed=99)
+    assert not torch.equal(y, y3)
+
+
+GEMM_CASES = [  # M, N, K
+    (16, 64, 64), (37, 128, 72), (2560, 2048, 2048), (256, 2048, 2048), (640, 3072, 768), (44, 8192, 768), (300, 200, 136),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_CASES)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", ["none", "relu"])
+def test_linear(M, N, K, dtype, act):
+    from mmgl_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) * 0.3
+    w = torch.randn(M, N, generator=g)
+    scale = 0.125 if act == "none" else 1.0
+    xd, Wd, bd = dev(x, dtype), dev(W, dtype), dev(b, dtype)
+    y = ops.linear(xd, Wd, bd, act=act, out_scale=scale)
+    (y * w.to(dtype).cuda()).sum().backward()
+    xr, Wr, br = (t.detach().float().cpu().requires_grad_() for t in (xd, Wd, bd))
+    yr = F.linear(xr, Wr, br) * scale
+    if act == "relu":
+        yr = F.relu(yr)
+    (yr * w.to(dtype).float()).sum().backward()
+    t = tol(dtype, 1e-4, 2e-2)
+    assert_close(y.float(), yr, t, "y")
+    assert_close(xd.grad.float(), xr.grad, t, "dx")
+    assert_close(Wd.grad.float(), Wr.grad, t, "dW")
+    assert_close(bd.grad.float(), br.grad, t, "db")
+
+
+def test_linear_a_is_identity_asymmetric():
+    """Transpose-detecting check: W = asymmetric matrix, x = identity."""
+    from mmgl_amd import ops
+    N = K = 128
+    W = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 251.0
+    x = torch.eye(K)
+    y = ops.linear(x.cuda(), W.cuda())
+    assert_close(y, W.t(), 1e-6, "identity")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_lora_linear(dtype):
+    from mmgl_amd import ops
+    M, N, K, r, s = 200, 256, 192, 16, 0.5
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    A = torch.randn(r, K, generator=g) * K ** -0.5
+    Bm = torch.randn(N, r, generator=g) * 0.3
+    w = torch.randn(M, N, generator=g)
+    xd, Ad, Bd = dev(x, dtype), dev(A, dtype), dev(Bm, dtype)
+    Wd, bd = W.to(dtype).cuda(), b.to(dtype).cuda()
+    y = ops.lora_linear(xd, Wd, bd, Ad, Bd, s)
+    (y * w.to(dtype).cuda()).sum().backward()
+    xr, Ar, Br = (t.detach().float().cpu().requires_grad_() for t in (xd, Ad, Bd))
+    yr = F.linear(xr, Wd.float().cpu(), bd.float().cpu()) + s * (xr @ Ar.t()) @ Br.t()
+    (yr * w.to(dtype).float()).sum().backward()
+    t = tol(dtype, 1e-4, 3e-2)
+    assert_close(y.float(), yr, t, "y")
+    assert_close(xd.grad.float(), xr.grad, t, "dx")
+    assert_close(Ad.grad.float(), Ar.grad, t, "dA")
+    assert_close(Bd.grad.float(), Br.grad, t, "dB")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_neighbor_interleave_vs_oracle(dtype):
+    from mmgl_amd import ops
+    from oracle import wrapper_ref
+    fx = Fixture("g1_wrapper_all.npz")
+    B, Nt, Ni, n, d = 2, 3, 2, 2, 64
+    g = torch.Generator().manual_seed(2)
+    te = torch.randn(B, Nt, n, d, generator=g)
+    ve = torch.randn(B, Ni, n, d, generator=g)
+    w = torch.randn(B, (Nt + Ni) * n, d, generator=g)
+    b = fx.inp
+    ted, ved = dev(te, dtype), dev(ve, dtype)
+    out, valid = ops.neighbor_interleave(ted, ved, b["text_locations"].cuda(), b["image_locations"].cuda(),
+                                         b["neighbor_pos_ids"].cuda(), b["neighbor_images_pos_ids"].cuda())
+    (out * w.to(dtype).cuda()).sum().backward()
+    ro, rv = wrapper_ref.interleave_neighbors(ted.detach().float().cpu(), ved.detach().float().cpu(), b["neighbor_pos_ids"],
+                                              b["neighbor_images_pos_ids"], b["text_locations"], b["image_locations"])
+    assert torch.equal(out.float().cpu(), ro)
+    assert torch.equal(valid.bool().cpu(), rv)
+    # gradient = gather of w
+    wv = w.to(dtype).float().view(B, Nt + Ni, n, d)
+    for bi in range(B):
+        for j in range(Nt):
+            assert torch.equal(ted.grad[bi, j].float().cpu(), wv[bi, b["text_locations"][bi, j]])
+        for j in range(Ni):
+            assert torch.equal(ved.grad[bi, j].float().cpu(), wv[bi, b["image_locations"][bi, j]])
+
+
+@pytest.mark.parametrize("rows,V", [(46, 128), (1278, 50272), (7, 32000)])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cross_entropy(rows, V, dtype):
+    from mmgl_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    logits = torch.randn(rows, V, generator=g) * 3
+    labels = torch.randint(0, V, (rows,), generator=g)
+    labels[::5] = -100
+    ld = dev(logits, dtype)
+    loss = ops.cross_entropy(ld, labels.cuda())
+    (loss * 1.7).backward()
+    lr = ld.detach().float().cpu().requires_grad_()
+    lossr = F.cross_entropy(lr, labels)
+    (lossr * 1.7).backward()
+    assert_close(loss.cpu(), lossr, 1e-5 if dtype == torch.float32 else 1e-4, "loss")
+    assert_close(ld.grad.float(), lr.grad, tol(dtype, 1e-4, 1e-2), "dlogits")
+
+
+def test_position_ids():
+    from mmgl_amd import ops
+    from oracle import lm_ref
+    g = torch.Generator().manual_seed(0)
+    m = (torch.rand(5, 700, generator=g) > 0.3).long()
+    m[0] = 1
+    m[1] = 0
+    assert torch.equal(ops.position_ids(m.cuda()).cpu(), lm_ref.learned_position_ids(m))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_adamw_matches_torch(dtype):
+    from mmgl_amd import ops
+    n = 10007
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(n, generator=g)
+    pref = p0.clone().requires_grad_()
+    opt = torch.optim.AdamW([pref], lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8)
+    p = p0.to(dtype).cuda()
+    master = p0.clone().cuda() if dtype == torch.bfloat16 else None
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        pref.grad = gr.to(dtype).float()
+        opt.step()
+        ops.adamw_step_(p, master, gr.to(dtype).cuda(), m, v, 1e-2, 0.9, 0.95, 1e-8, 0.01, step)
+    assert_close((master if master is not None else p).float().cpu(), pref.detach(), 1e-5, "adamw")

@@ -1,0 +1,121 @@
+"""-m gpu parity tests: HIP cross-attention core (through the C ABI) vs the CPU oracle."""
+import pytest
+import torch
+
+from helpers import Fixture, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(q, k, v, valid, H, w):
+    from oracle import lm_ref
+    q = q.detach().float().cpu().requires_grad_()
+    k = k.detach().float().cpu().requires_grad_()
+    v = v.detach().float().cpu().requires_grad_()
+    m4 = lm_ref.expand_mask(valid.cpu(), torch.float32, q.shape[1])
+    out = lm_ref.attention_core(q, k, v, m4, H)
+    (out * w.float().cpu()).sum().backward()
+    return out.detach(), q.grad, k.grad, v.grad
+
+
+def _masks(B, S, gen):
+    valid = torch.rand(B, S, generator=gen) > 0.35
+    valid[:, 0] = True
+    if B > 1:
+        valid[1, S // 2:] = False
+    if B > 2:
+        valid[2, :] = False            # fully masked sample
+    return valid
+
+
+CASES = [  # B, H, T, S, D
+    (3, 4, 16, 12, 16),      # tiny golden shape
+    (3, 2, 50, 10, 32),      # ragged T, D=32
+    (4, 12, 640, 16, 64),    # config 2: OPT-125m, 4 neighbors
+    (4, 32, 640, 64, 64),    # config 3: OPT-1.3B, 16 neighbors
+    (2, 32, 2176, 128, 128), # config 5: Llama-2-7B dims, 32 neighbors
+    (3, 3, 77, 200, 64),     # S > 128 path, odd sizes
+]
+
+
+@pytest.mark.parametrize("B,H,T,S,D", CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_xattn_fwd_bwd_vs_oracle(B, H, T, S, D, dtype):
+    from mmgl_amd import ops
+    gen = torch.Generator().manual_seed(1000 + B * 7 + T)
+    d = H * D
+    q = (torch.randn(B, T, d, generator=gen) * (D ** -0.5) * 2.0)
+    k = torch.randn(B, S, d, generator=gen)
+    v = torch.randn(B, S, d, generator=gen)
+    w = torch.randn(B, T, d, generator=gen)
+    valid = _masks(B, S, gen)
+    qd, kd, vd = (t.to(dtype).cuda().requires_grad_() for t in (q, k, v))
+    out = ops.xattn_core(qd, kd, vd, valid.cuda(), H)
+    (out * w.to(dtype).cuda()).sum().backward()
+    # oracle sees the same (possibly bf16-rounded) inputs, in fp32
+    ro, rq, rk, rv = _oracle(qd, kd, vd, valid, H, w.to(dtype))
+    assert torch.isfinite(out).all()
+    tol = 1e-3 if dtype == torch.float32 else 2e-2     # BASELINE: 1e-3 relative fp32; bf16 path: bf16 rounding of P/dS
+    assert_close(out.float(), ro, tol, "out")
+    assert_close(qd.grad.float(), rq, tol, "dq")
+    assert_close(kd.grad.float(), rk, tol, "dk")
+    assert_close(vd.grad.float(), rv, tol, "dv")
+
+
+def test_xattn_golden_g4():
+    """Golden vector produced by the reference itself (tests/golden/make_golden.py: G4)."""
+    from mmgl_amd import ops
+    import torch.nn.functional as F
+    fx = Fixture("g4_attention.npz")
+    H, D = fx.meta["H"], fx.meta["D"]
+    p = {k: v.cuda() for k, v in fx.p.items()}
+    hidden = fx.inp["hidden"].cuda()
+    ne = fx.inp["neighbor_embeds"].cuda()
+    q = (F.linear(hidden, p["q_proj.weight"], p["q_proj.bias"]) * D ** -0.5).requires_grad_()
+    k = F.linear(ne, p["k_proj.weight"], p["k_proj.bias"]).requires_grad_()
+    v = F.linear(ne, p["v_proj.weight"], p["v_proj.bias"]).requires_grad_()
+    o = ops.xattn_core(q, k, v, fx.inp["valid"].cuda(), H)
+    out = F.linear(o, p["out_proj.weight"], p["out_proj.bias"])
+    assert_close(out, fx.out["out"], 1e-3, "golden attention out")
+    (out * fx.inp["w"].cuda()).sum().backward()
+    dhidden = (q.grad * D ** -0.5) @ p["q_proj.weight"]
+    assert_close(dhidden, fx.grad["hidden"], 1e-3, "golden d hidden")
+    dne = k.grad @ p["k_proj.weight"] + v.grad @ p["v_proj.weight"]
+    assert_close(dne, fx.grad["neighbor_embeds"], 1e-3, "golden d neighbor_embeds")
+
+
+def test_xattn_properties_full_size():
+    """Size-independent properties at config-3 size: (i) masked keys do not influence the output,
+    (ii) output rows are convex combinations of V rows (bounded by V's range), (iii) determinism."""
+    from mmgl_amd import ops
+    B, H, T, S, D = 4, 32, 640, 64, 64
+    gen = torch.Generator().manual_seed(7)
+    q = torch.randn(B, T, H * D, generator=gen).cuda() * 0.3
+    k = torch.randn(B, S, H * D, generator=gen).cuda()
+    v = torch.randn(B, S, H * D, generator=gen).cuda()
+    valid = (torch.rand(B, S, generator=gen) > 0.4)
+    valid[:, 0] = True
+    valid = valid.cuda()
+    o1 = ops.xattn_core(q, k, v, valid, H)
+    k2, v2 = k.clone(), v.clone()
+    k2[~valid] = 1e3
+    v2[~valid] = -1e3
+    o2 = ops.xattn_core(q, k2, v2, valid, H)
+    assert torch.equal(o1, o2)
+    vmax = torch.where(valid[..., None], v, torch.full_like(v, -1e30)).amax(dim=1, keepdim=True)
+    vmin = torch.where(valid[..., None], v, torch.full_like(v, 1e30)).amin(dim=1, keepdim=True)
+    assert (o1 <= vmax + 1e-4).all() and (o1 >= vmin - 1e-4).all()
+    assert torch.equal(o1, ops.xattn_core(q, k, v, valid, H))
+
+
+def test_xattn_errors():
+    from mmgl_amd import ops
+    q = torch.randn(2, 8, 48, device="cuda")
+    k = torch.randn(2, 4, 48, device="cuda")
+    valid = torch.ones(2, 4, dtype=torch.bool, device="cuda")
+    with pytest.raises(ValueError):
+        ops.xattn_core(q, k, k, valid, 5)                 # embed_dim not divisible by heads
+    with pytest.raises(ValueError):
+        ops.xattn_core(q, k, k, valid[:, :3], 1)          # mask shape
+    with pytest.raises(ValueError):
+        ops.xattn_core(q, k, k, valid, 1)                 # head_dim 48 unsupported
