@@ -133,6 +133,11 @@ def test_linear(M, N, K, dtype, act):
     w = torch.randn(M, N, generator=g)
     scale = 0.125 if act == "none" else 1.0
     xd, Wd, bd = dev(x, dtype), dev(W, dtype), dev(b, dtype)
+    if act == "relu":
+        # keep the test away from the ReLU kink: outputs whose pre-activation is ~0 may legitimately land on either
+        # side depending on summation order, so they get zero weight in the scalar that is differentiated
+        pre = F.linear(xd.detach().float().cpu(), Wd.detach().float().cpu(), bd.detach().float().cpu())
+        w = w * (pre.abs() > (1e-3 if dtype == torch.float32 else 5e-2))
     y = ops.linear(xd, Wd, bd, act=act, out_scale=scale)
     (y * w.to(dtype).cuda()).sum().backward()
     xr, Wr, br = (t.detach().float().cpu().requires_grad_() for t in (xd, Wd, bd))
