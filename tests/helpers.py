@@ -42,3 +42,43 @@ def assert_close(a, b, tol, what=""):
     e = rel_err(a, b)
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
     return e
+
+
+# ------------------------------------------------------------------------------------------ tiny model builders
+def tiny_opt_config(pre_ln=True, proj=None, dropout=0.1):
+    from transformers import OPTConfig
+    return OPTConfig(vocab_size=128, hidden_size=64, num_attention_heads=4, ffn_dim=128, num_hidden_layers=4,
+                     max_position_embeddings=64, word_embed_proj_dim=proj or 64, do_layer_norm_before=pre_ln,
+                     dropout=dropout, attention_dropout=0.0, pad_token_id=1, bos_token_id=2, eos_token_id=2, init_std=0.08)
+
+
+def tiny_roberta_config():
+    from transformers import RobertaConfig
+    return RobertaConfig(vocab_size=128, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                         max_position_embeddings=40, pad_token_id=1, type_vocab_size=1, hidden_dropout_prob=0.0,
+                         attention_probs_dropout_prob=0.0)
+
+
+def tiny_clip_vision_config():
+    from transformers import CLIPVisionConfig
+    return CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, image_size=32,
+                            patch_size=16)
+
+
+def mpt_args(**kw):
+    from types import SimpleNamespace
+    a = dict(context="all", neighbor_mode="cross_attention", n_text_tokens=2, n_visual_tokens=2, text_model="roberta-tiny",
+             visual_model="clip-vit-tiny", max_output_length=8, freeze_lm=False, model_name_or_path="opt-tiny",
+             peft_type="flamingo", lora_r=4, lora_alpha=1.0, lora_dropout=0.0, neighbor_layer_wise=2, decoder_only=True,
+             position_type="none", max_text_neighbors=3, max_image_neighbors=2)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def load_exact(module, state, prefix=""):
+    """load_state_dict(strict) from a fixture group, ignoring fixture keys outside `prefix`."""
+    sd = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)}
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if "position_ids" not in k]
+    assert not missing, f"missing keys: {missing[:5]}"
+    assert not [k for k in unexpected if "position_ids" not in k], f"unexpected keys: {unexpected[:5]}"

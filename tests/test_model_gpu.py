@@ -1,0 +1,140 @@
+"""-m gpu: the module-level API (mmgl_amd.model) against golden vectors captured from the reference itself
+(tests/golden/make_golden.py) and against the CPU oracle.  Tolerance: 1e-3 relative fp32 (BASELINE.json)."""
+import pytest
+import torch
+
+from helpers import (Fixture, assert_close, load_exact, mpt_args, tiny_clip_vision_config, tiny_opt_config,
+                     tiny_roberta_config)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def test_g5_decoder_layer_fwd_bwd():
+    from mmgl_amd.model.modelling_cross_attention import MPTConfig, MPTDecoderLayer
+    for name in ("g5_layer_preln.npz", "g5_layer_postln.npz"):
+        fx = Fixture(name)
+        cfg = MPTConfig(mpt_args(), tiny_opt_config(pre_ln=fx.meta["pre_ln"]))
+        layer = MPTDecoderLayer(cfg, cross_attention=True).cuda().eval()
+        load_exact(layer, fx.p)
+        hidden = fx.inp["hidden"].cuda().requires_grad_()
+        ne = fx.inp["neighbor_embeds"].cuda().requires_grad_()
+        out = layer(hidden, attention_mask=None, neighbor_embeds=ne, neighbor_attention_mask=fx.inp["valid"].cuda())[0]
+        assert_close(out, fx.out["out"], TOL, f"{name} out")
+        (out * fx.inp["w"].cuda()).sum().backward()
+        assert_close(hidden.grad, fx.grad["hidden"], TOL, "d hidden")
+        assert_close(ne.grad, fx.grad["neighbor_embeds"], TOL, "d neighbor_embeds")
+        for k, p in layer.named_parameters():
+            assert_close(p.grad, fx.grad[k], TOL, f"{name} d {k}")
+        # the reference's 4-D additive mask is accepted too
+        from oracle import lm_ref
+        m4 = lm_ref.expand_mask(fx.inp["valid"], torch.float32, hidden.shape[1]).cuda()
+        out2 = layer(hidden.detach(), neighbor_embeds=ne.detach(), neighbor_attention_mask=m4)[0]
+        assert torch.equal(out2, out)
+
+
+def test_g3_fork_without_neighbors_equals_hf_opt():
+    from mmgl_amd.model.modelling_cross_attention import MPTConfig, MPTForCausalLM
+    for name in ("g3_lm_raw_preln.npz", "g3_lm_raw_postln_proj.npz"):
+        fx = Fixture(name)
+        oc = tiny_opt_config(pre_ln=fx.meta["pre_ln"], proj=fx.meta["proj"])
+        lm = MPTForCausalLM(MPTConfig(mpt_args(neighbor_mode="raw", peft_type="none"), oc)).cuda().eval()
+        load_exact(lm, fx.p)
+        b = {k: v.cuda() for k, v in fx.inp.items()}
+        with torch.no_grad():
+            o = lm(**b)
+        assert_close(o.logits, fx.out["logits"], TOL, f"{name} logits vs reference fork")
+        assert_close(o.logits, fx.out["hf_logits"], TOL, f"{name} logits vs HF OPT")
+        assert_close(o.loss, fx.out["loss"], TOL, f"{name} loss")
+
+
+def _build_wrapper(fx, context):
+    from mmgl_amd.model import CrossAttentionModel
+    w = CrossAttentionModel(mpt_args(context=context), tokenizer=None, lm_config=tiny_opt_config(),
+                            text_config=tiny_roberta_config(), visual_config=tiny_clip_vision_config())
+    load_exact(w, fx.p)
+    return w.cuda().eval()
+
+
+@pytest.mark.parametrize("tag,context", [("all", "all"), ("text_only", "text_only")])
+def test_g1_wrapper_logits_loss_grads(tag, context):
+    fx = Fixture(f"g1_wrapper_{tag}.npz")
+    w = _build_wrapper(fx, context)
+    trainable = sorted(k for k, p in w.named_parameters() if p.requires_grad)
+    assert trainable == fx.meta["trainable"], "trainable parameter set differs from the reference (DDP gradient set)"
+    b = {k: v.cuda() for k, v in fx.inp.items()}
+    if context == "text_only":
+        for k in ("neighbor_images", "neighbor_images_pos_ids", "image_locations"):
+            b.pop(k)
+    o = w(**b)
+    assert_close(o.logits, fx.out["logits"], TOL, "logits")
+    assert_close(o.loss, fx.out["loss"], TOL, "loss")
+    o.loss.backward()
+    params = dict(w.named_parameters())
+    for k, g in fx.grad.items():
+        assert params[k].grad is not None, f"no grad for {k}"
+        assert_close(params[k].grad, g, 2e-3, f"d {k}")
+    for k in fx.meta["trainable"]:
+        if k not in fx.meta["nograd"]:
+            assert params[k].grad is not None, k         # DDP(find_unused_parameters=False) contract
+
+
+def test_gates_zero_means_neighbors_are_ignored():
+    fx = Fixture("g1_wrapper_all.npz")
+    w = _build_wrapper(fx, "all")
+    with torch.no_grad():
+        for n_, p in w.named_parameters():
+            if n_.endswith("gating1") or n_.endswith("gating2"):
+                p.zero_()
+    b = {k: v.cuda() for k, v in fx.inp.items()}
+    with torch.no_grad():
+        a = w(**b).logits
+        b2 = dict(b)
+        b2["neighbor_images"] = torch.randn_like(b["neighbor_images"])
+        b2["neighbor_input_ids"] = b["neighbor_input_ids"].flip(-1).clamp_min(3)
+        c = w(**b2).logits
+    assert torch.equal(a, c)
+
+
+def test_bf16_wrapper_runs_and_tracks_fp32():
+    """model.bfloat16() path (run_generation --bf16): crashes in the reference (fp32 scratch); here it runs
+    and its logits track the fp32 golden within bf16 accuracy."""
+    fx = Fixture("g1_wrapper_all.npz")
+    w = _build_wrapper(fx, "all").bfloat16()
+    b = {k: v.cuda() for k, v in fx.inp.items()}
+    o = w(**b)
+    assert o.logits.dtype == torch.bfloat16
+    assert_close(o.logits.float(), fx.out["logits"], 6e-2, "bf16 logits")
+    o.loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in w.parameters() if p.grad is not None)
+
+
+def test_train_mode_dropout_and_eval_returns_self():
+    fx = Fixture("g1_wrapper_all.npz")
+    w = _build_wrapper(fx, "all")
+    assert w.train() is w and w.eval() is w
+    w.train()
+    assert not w.text_model.training and not w.visual_model.training and w.lm.training
+    b = {k: v.cuda() for k, v in fx.inp.items()}
+    l1 = w(**b).loss
+    l2 = w(**b).loss
+    assert torch.isfinite(l1) and l1.item() != l2.item()      # dropout p=0.1 is live (reference :332, :356)
+    l1.backward()
+
+
+def test_value_errors_match_reference():
+    from mmgl_amd.model import CrossAttentionModel
+    from mmgl_amd.model.modelling_cross_attention import MPTConfig, MPTAttention
+    with pytest.raises(ValueError):
+        oc = tiny_opt_config()
+        oc.num_attention_heads = 5
+        MPTAttention(MPTConfig(mpt_args(), oc), True)
+    fx = Fixture("g1_wrapper_all.npz")
+    w = _build_wrapper(fx, "all")
+    w.context = "bogus"
+    b = {k: v.cuda() for k, v in fx.inp.items()}
+    with pytest.raises(ValueError):
+        w(**b)
+    with pytest.raises(ValueError):
+        CrossAttentionModel(mpt_args(n_visual_tokens=3), None, lm_config=tiny_opt_config(), text_config=tiny_roberta_config(),
+                            visual_config=tiny_clip_vision_config())
