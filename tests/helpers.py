@@ -30,12 +30,13 @@ class Fixture:
         return self.groups["in"]
 
 
-def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
-    """max|a-b| / max|b| -- the 'relative fp32' measure BASELINE.json's 1e-3 tolerance is stated in."""
+def rel_err(a: torch.Tensor, b: torch.Tensor, floor: float = 1e-6) -> float:
+    """max|a-b| / max(max|b|, floor) -- the 'relative fp32' measure BASELINE.json's 1e-3 tolerance is stated in.
+    The floor keeps analytically-zero tensors (e.g. d k_proj.bias: softmax is invariant to a per-row score shift)
+    from turning 1e-10 round-off into a relative error."""
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
-    denom = b.abs().max().item()
-    return (a - b).abs().max().item() / (denom if denom > 0 else 1.0)
+    return (a - b).abs().max().item() / max(b.abs().max().item(), floor)
 
 
 def assert_close(a, b, tol, what=""):

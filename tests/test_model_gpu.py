@@ -25,6 +25,9 @@ def test_g5_decoder_layer_fwd_bwd():
         assert_close(hidden.grad, fx.grad["hidden"], TOL, "d hidden")
         assert_close(ne.grad, fx.grad["neighbor_embeds"], TOL, "d neighbor_embeds")
         for k, p in layer.named_parameters():
+            if k.endswith("k_proj.bias"):     # analytically zero (softmax ignores a per-row score shift): round-off only
+                assert p.grad.abs().max() < 1e-5 and fx.grad[k].abs().max() < 1e-5
+                continue
             assert_close(p.grad, fx.grad[k], TOL, f"{name} d {k}")
         # the reference's 4-D additive mask is accepted too
         from oracle import lm_ref
@@ -73,6 +76,9 @@ def test_g1_wrapper_logits_loss_grads(tag, context):
     params = dict(w.named_parameters())
     for k, g in fx.grad.items():
         assert params[k].grad is not None, f"no grad for {k}"
+        if k.endswith("k_proj.bias"):
+            assert params[k].grad.abs().max() < 1e-5 and g.abs().max() < 1e-5
+            continue
         assert_close(params[k].grad, g, 2e-3, f"d {k}")
     for k in fx.meta["trainable"]:
         if k not in fx.meta["nograd"]:
