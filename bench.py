@@ -1,0 +1,284 @@
+#!/usr/bin/env python
+"""bench.py -- the reference's headline metric on MI355X.
+
+    python bench.py --gpus 1 --steps 8 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+metric   : train samples/sec (whole job) of the neighbor-fusion fine-tune -- frozen RoBERTa-base + CLIP ViT-B/16
+           over every neighbor, OPT-1.3B with 4 gated cross-attention layers (flamingo), 16 neighbors x 4 tokens,
+           T = 512 + 128 -- one "step" = forward + backward + gradient exchange + AdamW on one synthetic
+           WikiWeb2M-shaped batch per GPU (BASELINE.json configs[2] per GPU, which fits one GPU).
+           samples/sec/GPU = value / n_gpus (the reference's examples_per_sec / ngpus, run_generation.py:503).
+roofline : the masked cross-attention core (mmgl_xattn_fwd), the north-star kernel: HBM-bound.  achieved =
+           algorithmic bytes per launch (sum over samples of 2*T*d*e + 2*S_valid*d*e) / average
+           launch duration measured with HIP events on the launch stream inside the timed steps.
+cpu_baseline: the CPU oracle (oracle/, fp32 torch restatement pinned to the reference's golden vectors) running the
+           same step (encoders + LM forward/backward) on a bounded sample on the host cores; kind "port".
+Data are synthetic (seeded) and weights random-init of the named architectures: no network in this environment.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured-achievable
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
+MFMA_F32_PEAK_TF = 157.3
+
+CONFIGS = {
+    # name: (lm dims, neighbors)
+    "opt-1.3b": dict(lm=dict(vocab_size=50272, hidden_size=2048, num_attention_heads=32, ffn_dim=8192, num_hidden_layers=24,
+                             max_position_embeddings=2048, word_embed_proj_dim=2048), nt=11, ni=5, wise=6,
+                     model_name="facebook/mpt-1.3b"),
+    "opt-125m": dict(lm=dict(vocab_size=50272, hidden_size=768, num_attention_heads=12, ffn_dim=3072, num_hidden_layers=12,
+                             max_position_embeddings=2048, word_embed_proj_dim=768), nt=2, ni=2, wise=3,
+                     model_name="facebook/mpt-125m"),
+}
+
+
+def hf_configs(cfg):
+    from transformers import CLIPVisionConfig, OPTConfig, RobertaConfig
+    lm = OPTConfig(do_layer_norm_before=True, dropout=0.1, attention_dropout=0.0, pad_token_id=1, bos_token_id=2,
+                   eos_token_id=2, **cfg["lm"])
+    txt = RobertaConfig(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                        max_position_embeddings=514, pad_token_id=1, type_vocab_size=1)
+    vis = CLIPVisionConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                           image_size=224, patch_size=16, projection_dim=512)
+    return lm, txt, vis
+
+
+def make_args(cfg, **kw):
+    from mmgl_amd.language_modelling.run_generation import Arguments
+    a = Arguments(model_name_or_path=cfg["model_name"], context="all", neighbor_mode="embedding", peft_type="flamingo",
+                  max_text_neighbors=cfg["nt"], max_image_neighbors=cfg["ni"], decoder_only=True)
+    a.neighbor_layer_wise = cfg["wise"]
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def synthetic_batch(B, cfg, seed, device, Lin=512, Lout=128, Ln=512, vocab=50272):
+    """WikiWeb2M-shaped batch of SURVEY.md 8(d): ragged prompt / summary / neighbor lengths, ragged neighbor counts,
+    random interleave of the valid slots, padding slots last."""
+    g = torch.Generator().manual_seed(seed)
+    Nt, Ni = cfg["nt"], cfg["ni"]
+    T = Lin + Lout
+    ids = torch.randint(3, vocab, (B, T), generator=g)
+    am = torch.ones(B, T, dtype=torch.long)
+    nids = torch.randint(3, 50265, (B, Nt, Ln), generator=g)
+    nam = torch.ones(B, Nt, Ln, dtype=torch.long)
+    npos = torch.zeros(B, Nt, dtype=torch.long)
+    ipos = torch.zeros(B, Ni, dtype=torch.long)
+    tloc = torch.zeros(B, Nt, dtype=torch.long)
+    iloc = torch.zeros(B, Ni, dtype=torch.long)
+    imgs = torch.zeros(B, Ni, 3, 224, 224)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for b in range(B):
+        lp, ls = ri(64, Lin), ri(8, 64)
+        ids[b, lp:Lin] = 1; am[b, lp:Lin] = 0
+        ids[b, Lin + ls - 1] = 2; ids[b, Lin + ls:] = 1; am[b, Lin + ls:] = 0
+        nt, ni = ri(1, Nt), ri(0, Ni)
+        for j in range(Nt):
+            if j < nt:
+                ln = ri(16, Ln)
+                nids[b, j, 0] = 0; nids[b, j, ln - 1] = 2; nids[b, j, ln:] = 1; nam[b, j, ln:] = 0
+                npos[b, j] = j + 1
+            else:
+                nids[b, j] = 1; nids[b, j, 0] = 0; nids[b, j, 1] = 2; nam[b, j, 2:] = 0
+        for j in range(ni):
+            imgs[b, j] = torch.randn(3, 224, 224, generator=g)
+            ipos[b, j] = j + 1
+        kinds = ["t"] * (nt - 1) + ["i"] * ni
+        perm = torch.randperm(len(kinds), generator=g).tolist()
+        order = ["t"] + [kinds[q] for q in perm]
+        ti = ii = 0
+        for loc, kd in enumerate(order):
+            if kd == "t":
+                tloc[b, ti] = loc; ti += 1
+            else:
+                iloc[b, ii] = loc; ii += 1
+        loc = len(order)
+        for j in range(nt, Nt):
+            tloc[b, j] = loc; loc += 1
+        for j in range(ni, Ni):
+            iloc[b, j] = loc; loc += 1
+    batch = dict(input_ids=ids, attention_mask=am, labels=ids.clone(), neighbor_input_ids=nids, neighbor_attention_mask=nam,
+                 neighbor_pos_ids=npos, text_locations=tloc, neighbor_images=imgs, neighbor_images_pos_ids=ipos,
+                 image_locations=iloc)
+    valid_keys = [(int((npos[b] > 0).sum()) + int((ipos[b] > 0).sum())) * 4 for b in range(B)]
+    return {k: v.to(device) for k, v in batch.items()}, valid_keys
+
+
+def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1):
+    """Time the CPU oracle on the same step (frozen encoders fwd, LM fwd+bwd w.r.t. the trainable set) for a bounded
+    sample.  fp32, all host cores.  Returns the JSON object for the bench line."""
+    from oracle import lm_ref, wrapper_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t_build = time.time()
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad]
+    for k in trainable:
+        sd[k].requires_grad_()
+    text_model = model.text_model.float().cpu()
+    visual_model = model.visual_model.float().cpu()
+    b = {k: v[:n_samples].cpu() for k, v in batch.items()}
+    ocfg = lm_ref.LMConfig(vocab_size=lm_cfg.vocab_size, hidden_size=lm_cfg.hidden_size, num_attention_heads=lm_cfg.num_attention_heads,
+                           ffn_dim=lm_cfg.ffn_dim, num_hidden_layers=lm_cfg.num_hidden_layers,
+                           word_embed_proj_dim=lm_cfg.word_embed_proj_dim, neighbor_layer_wise=cfg["wise"])
+    t0 = time.time()
+    with torch.no_grad():
+        L = b["neighbor_input_ids"].shape[-1]
+        tl = text_model(input_ids=b["neighbor_input_ids"].reshape(-1, L), attention_mask=b["neighbor_attention_mask"].reshape(-1, L)).last_hidden_state
+        vp = visual_model(b["neighbor_images"].reshape(-1, 3, 224, 224)).pooler_output
+    logits, loss = wrapper_ref.cross_attention_model_forward(sd, ocfg, b, tl, vp, "all", 4)
+    loss.backward()
+    dt = time.time() - t0
+    model.text_model.to(batch["input_ids"].device)
+    model.visual_model.to(batch["input_ids"].device)
+    return dict(value=n_samples / dt, unit="samples/s", cores=cores, kind="port", seconds=round(dt, 2),
+                sample=f"{n_samples} sample(s) of the same synthetic batch: frozen encoders fwd + LM fwd + bwd (no optimizer step), "
+                       f"fp32 torch oracle (oracle/), {cores} threads", loss=float(loss))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="opt-1.3b", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (reference default 4; sized for 288 GB HBM)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=1)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from mmgl_amd import _lib
+    from mmgl_amd.distributed import DataParallelEngine
+    from mmgl_amd.model import CrossAttentionModel
+    _lib.lib()                                        # fail loudly if the HIP extension is missing
+
+    cfg = CONFIGS[args.config]
+    lm_cfg, txt_cfg, vis_cfg = hf_configs(cfg)
+    margs = make_args(cfg)
+    torch.manual_seed(1234)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    with torch.device("cpu"):
+        model = CrossAttentionModel(margs, tokenizer=None, lm_config=lm_cfg, text_config=txt_cfg, visual_config=vis_cfg)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.endswith("gating1") or n_.endswith("gating2"):
+                p.fill_(0.5)                          # numerically live cross-attention (init value 0 = identity)
+    model = model.to(dtype).to(device)
+    model.train()
+    engine = DataParallelEngine(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.01)
+    n_train = sum(p.numel() for p in engine.params)
+
+    batch, valid_keys = synthetic_batch(args.batch, cfg, seed=1234 + rank, device=device)
+    T = batch["input_ids"].shape[1]
+    d = lm_cfg.hidden_size
+    esize = 2 if dtype == torch.bfloat16 else 4
+
+    def step():
+        out = model(**batch)
+        out.loss.backward()
+        engine.finish_backward()
+        engine.step()
+        engine.zero_grad()
+        return out.loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    timing = not args.no_kernel_timing
+    _lib.KernelTimer.reset()
+    _lib.KernelTimer.enabled = timing
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.KernelTimer.enabled = False
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        value = world * args.batch * args.steps / dt
+        line = {
+            "metric": "train samples/sec (OPT-1.3B flamingo, 16 neighbors)" if args.config == "opt-1.3b"
+                      else f"train samples/sec ({args.config} flamingo)",
+            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic WikiWeb2M-shaped batch (seeded), random-init weights",
+            "samples_per_sec_per_gpu": round(value / world, 3),
+            "config": {"workload": f"{args.config} context=all neighbor_mode=embedding peft=flamingo, {cfg['nt']}+{cfg['ni']} neighbors x 4 tokens, "
+                                   f"T=640, roberta-base + clip-vit-base-patch16 frozen encoders, full train step (fwd+bwd+exchange+AdamW)",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "seq_len": T, "neighbor_keys": (cfg["nt"] + cfg["ni"]) * 4,
+                       "trainable_params": n_train, "parallelism": f"dp{world}", "loss": round(float(loss), 4)},
+        }
+        if timing:
+            ks = _lib.KernelTimer.summary()
+            x = ks.get("mmgl_xattn_fwd")
+            if x:
+                alg = sum(2.0 * T * d * esize + 2.0 * sv * d * esize for sv in valid_keys)     # bytes per launch
+                flops = sum(4.0 * T * sv * d for sv in valid_keys)
+                sec = x["ms_avg"] * 1e-3
+                gbs = alg / sec / 1e9
+                line["roofline"] = {"kernel": "xattn_fwd_kernel (mmgl_xattn_fwd)", "bound": "hbm", "achieved": round(gbs, 1),
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                    "us_per_launch": round(x["ms_avg"] * 1e3, 2), "launches": x["calls"],
+                                    "algorithmic_bytes_per_launch": alg, "tflops": round(flops / sec / 1e12, 2),
+                                    "frac_of_bf16_mfma_peak": round(flops / sec / 1e12 / MFMA_BF16_PEAK_TF, 4)}
+            peak_tf = MFMA_BF16_PEAK_TF if dtype == torch.bfloat16 else MFMA_F32_PEAK_TF
+            kern = {}
+            for name, s in sorted(ks.items(), key=lambda kv: -kv[1]["ms_total"]):
+                e = {"calls": s["calls"], "ms_avg": round(s["ms_avg"], 4), "ms_total": round(s["ms_total"], 2)}
+                if s["flops"]:
+                    tf = s["flops"] / (s["ms_total"] * 1e-3) / 1e12
+                    e.update(bound="mfma", tflops=round(tf, 1), frac=round(tf / peak_tf, 4))
+                elif s["bytes"]:
+                    gb = s["bytes"] / (s["ms_total"] * 1e-3) / 1e9
+                    e.update(bound="hbm", gbs=round(gb, 1), frac=round(gb / HBM_PEAK_GBS, 4))
+                kern[name] = e
+            xb = ks.get("mmgl_xattn_bwd")
+            if xb:
+                alg_b = sum(3.0 * T * d * esize + 4.0 * sv * d * esize for sv in valid_keys)
+                gb = alg_b / (xb["ms_avg"] * 1e-3) / 1e9
+                kern["mmgl_xattn_bwd"].update(bound="hbm", gbs=round(gb, 1), frac=round(gb / HBM_PEAK_GBS, 4))
+            line["kernels"] = kern
+            line["hip_path_ms_per_step"] = round(sum(s["ms_total"] for s in ks.values()) / args.steps, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, cfg, lm_cfg, batch, args.cpu_samples)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

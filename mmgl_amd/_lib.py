@@ -100,3 +100,44 @@ def require_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
             raise RuntimeError("mmgl_amd ops run on the GPU only (tensor is on %s); there is no CPU path" % t.device)
+
+
+class KernelTimer:
+    """Optional per-entry-point timing with HIP events on torch's current stream (= the stream the kernels are launched
+    on).  Off by default (zero overhead); bench.py turns it on to price each C-ABI call against its roofline."""
+    enabled = False
+    records = []          # (name, start_event, end_event, work dict)
+
+    @classmethod
+    def reset(cls):
+        cls.records = []
+
+    @classmethod
+    def summary(cls):
+        """name -> dict(calls, ms_total, ms_avg, bytes, flops) after a device synchronize."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, work in cls.records:
+            d = out.setdefault(name, dict(calls=0, ms_total=0.0, bytes=0.0, flops=0.0))
+            d["calls"] += 1
+            d["ms_total"] += s.elapsed_time(e)
+            d["bytes"] += work.get("bytes", 0.0)
+            d["flops"] += work.get("flops", 0.0)
+        for d in out.values():
+            d["ms_avg"] = d["ms_total"] / d["calls"]
+        return out
+
+
+def call(name: str, work, *args):
+    """Invoke C-ABI entry point `name`; raises ValueError / RuntimeError on a non-zero return code."""
+    fn = getattr(lib(), name)
+    if KernelTimer.enabled:
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*args)
+        e.record()
+        KernelTimer.records.append((name, s, e, work() if callable(work) else (work or {})))
+    else:
+        rc = fn(*args)
+    check(rc, name)

@@ -1,0 +1,199 @@
+"""Data-parallel gradient exchange + fused optimizer for the neighbor-fusion path (one process per GPU).
+
+Replaces `torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu], find_unused_parameters=False)` +
+`torch.optim.AdamW` of the reference (language_modelling/run_generation.py:317-333, 484-494) with an
+xGMI-shaped design:
+
+  * every trainable parameter is a view into ONE flat parameter buffer and its .grad a view into ONE flat gradient
+    buffer, laid out in expected grad-ready order (last cross-attention layer first), so autograd accumulates
+    straight into communication-ready memory and the optimizer is a single fused HIP kernel over the flat buffers
+    (mmgl_adamw_step) instead of ~100 small per-tensor launches;
+  * the flat gradient is cut into few LARGE contiguous buckets (default 256 MiB; xGMI is point-to-point, 7 links x
+    ~153 GB/s per GPU, so RCCL's ring/direct algorithms want big messages, not DDP's 25 MiB NVSwitch-era buckets);
+    a bucket's all-reduce is launched from a post-accumulate-grad hook the moment its last gradient lands, so the
+    exchange overlaps the rest of backward on RCCL's own stream;
+  * gradients are exchanged ONCE PER OPTIMIZER STEP (set `sync=False` on the non-final micro-batches): the reference
+    all-reduces on every micro-batch because it never uses no_sync() (run_generation.py:484-485); the sum is the same
+    up to summation order, the wire traffic is grad_accumulation_steps x smaller;
+  * the 1/world_size averaging is folded into the optimizer kernel's grad_scale: no extra pass over the gradients.
+
+`torch.distributed` (backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests) carries the collectives.
+"""
+import re
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def _grad_ready_order(named_params):
+    """neighbor_layers.N descending (backward reaches the last cross-attention layer first), everything else
+    (neighbor projections, poolers, embeddings: fed by ALL cross-attention layers, so ready last) afterwards."""
+    pat = re.compile(r"neighbor_layers\.(\d+)\.")
+    def key(item):
+        idx, (name, _) = item
+        m = pat.search(name)
+        return (0, -int(m.group(1)), -idx) if m else (1, 0, -idx)
+    return [np for _, np in sorted(enumerate(named_params), key=key)]
+
+
+class DataParallelEngine:
+    def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.95), eps: float = 1e-8,
+                 weight_decay: float = 0.01, bucket_mb: int = 256, process_group=None, master_weights: Optional[bool] = None,
+                 fused: Optional[bool] = None, broadcast: bool = True):
+        self.model = model
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.sync = True
+
+        named = _grad_ready_order([(n, p) for n, p in model.named_parameters() if p.requires_grad])
+        if not named:
+            raise ValueError("DataParallelEngine: the model has no trainable parameters")
+        seen, uniq = set(), []
+        for n, p in named:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append((n, p))
+        self.names = [n for n, _ in uniq]
+        self.params = [p for _, p in uniq]
+        p0 = self.params[0]
+        self.device, self.dtype = p0.device, p0.dtype
+        if any(p.dtype != self.dtype or p.device != self.device for p in self.params):
+            raise ValueError("DataParallelEngine: trainable parameters must share one dtype and device")
+        self.fused = self.device.type == "cuda" if fused is None else fused
+        if master_weights is None:
+            master_weights = self.dtype != torch.float32
+
+        # ---- flat buffers (each tensor starts on a 128-element boundary: 256/512-byte aligned views)
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 127) // 128 * 128
+        self.numel = off
+        self.flat_param = torch.zeros(off, dtype=self.dtype, device=self.device)
+        self.flat_grad = torch.zeros(off, dtype=self.dtype, device=self.device)
+        for p, o in zip(self.params, self.offsets):
+            self.flat_param[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[o:o + p.numel()].view(p.shape)
+            p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        if broadcast and self.world > 1:             # DDP's constructor broadcast of parameters (run_generation.py:319)
+            dist.broadcast(self.flat_param, src=0, group=self.pg)
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.master = self.flat_param.float() if master_weights else None
+
+        # ---- buckets = contiguous ranges of the flat gradient, closed in grad-ready order
+        cap = max(1, bucket_mb * (1 << 20) // self.flat_grad.element_size())
+        self.buckets: List[Dict] = []
+        start, members = 0, []
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            members.append(i)
+            end = self.offsets[i + 1] if i + 1 < len(self.params) else self.numel
+            if end - start >= cap or i + 1 == len(self.params):
+                self.buckets.append(dict(start=start, end=end, members=members, pending=len(members), work=None))
+                start, members = end, []
+        self._bucket_of = {}
+        for b in self.buckets:
+            for i in b["members"]:
+                self._bucket_of[i] = b
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+        self.exchange_bytes = 0
+
+    # ---------------------------------------------------------------------------------- gradient exchange
+    def _make_hook(self, i):
+        def hook(param):
+            want = self.flat_grad[self.offsets[i]:self.offsets[i] + param.numel()]
+            if param.grad is None or param.grad.data_ptr() != want.data_ptr():
+                # autograd replaced the view (first accumulation into an undefined grad): fold it back into the flat buffer
+                if param.grad is not None:
+                    want.add_(param.grad.reshape(-1).to(want.dtype))
+                param.grad = want.view(param.shape)
+            b = self._bucket_of[i]
+            b["pending"] -= 1
+            if b["pending"] == 0 and self.sync and self.world > 1:
+                b["work"] = dist.all_reduce(self.flat_grad[b["start"]:b["end"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                self.exchange_bytes += (b["end"] - b["start"]) * self.flat_grad.element_size()
+        return hook
+
+    def finish_backward(self):
+        """Call after loss.backward(): waits for the bucket all-reduces (if this was a sync step) and re-arms the hooks.
+        A parameter that received no gradient leaves its bucket open: launched here (find_unused_parameters=False is a
+        contract of the reference, so this is the rare path)."""
+        if self.sync and self.world > 1:
+            for b in self.buckets:
+                if b["work"] is None:
+                    b["work"] = dist.all_reduce(self.flat_grad[b["start"]:b["end"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    self.exchange_bytes += (b["end"] - b["start"]) * self.flat_grad.element_size()
+            for b in self.buckets:
+                b["work"].wait()
+        for b in self.buckets:
+            b["pending"], b["work"] = len(b["members"]), None
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p, o in zip(self.params, self.offsets):       # optimizer.zero_grad(set_to_none) callers must not detach the views
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad[o:o + p.numel()].data_ptr():
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    # ---------------------------------------------------------------------------------- optimizer
+    def step(self, lr: Optional[float] = None):
+        """AdamW (torch.optim.AdamW formula) over the flat buffers; gradients are averaged over ranks via grad_scale."""
+        lr = self.lr if lr is None else lr
+        self.step_count += 1
+        scale = 1.0 / self.world
+        b1, b2 = self.betas
+        if self.fused:
+            from . import ops
+            ops.adamw_step_(self.flat_param, self.master, self.flat_grad, self.exp_avg, self.exp_avg_sq, lr, b1, b2, self.eps,
+                            self.weight_decay, self.step_count, scale)
+            return
+        # reference formula in plain torch (CPU tests of the exchange logic only)
+        g = self.flat_grad.float() * scale
+        p = self.master if self.master is not None else self.flat_param
+        p.mul_(1 - lr * self.weight_decay)
+        self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
+        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1 = 1 - b1 ** self.step_count
+        bc2 = 1 - b2 ** self.step_count
+        denom = (self.exp_avg_sq.sqrt() / bc2 ** 0.5).add_(self.eps)
+        p.addcdiv_(self.exp_avg, denom, value=-lr / bc1)
+        if self.master is not None:
+            self.flat_param.copy_(self.master)
+
+    def grad_norm(self) -> torch.Tensor:
+        return self.flat_grad.float().norm() / self.world
+
+    # ---------------------------------------------------------------------------------- checkpointing
+    def state_dict(self):
+        """Same layout as torch.optim.AdamW.state_dict() over self.params in order (reference ckpt 'optimizer', :411)."""
+        state = {}
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            n = p.numel()
+            state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=self.exp_avg[o:o + n].view(p.shape).clone(),
+                            exp_avg_sq=self.exp_avg_sq[o:o + n].view(p.shape).clone())
+        group = dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, amsgrad=False,
+                     params=list(range(len(self.params))))
+        return dict(state=state, param_groups=[group], param_names=list(self.names))
+
+    def load_state_dict(self, sd):
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            n = p.numel()
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            self.step_count = int(st["step"])
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        if self.master is not None:
+            self.master.copy_(self.flat_param.float())
+
+    def sync_master_from_params(self):
+        """After load_state_dict on the model: refresh the fp32 master copy."""
+        if self.master is not None:
+            self.master.copy_(self.flat_param.float())

@@ -8,7 +8,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import check, dtype_code, lib, ptr, require_cuda, stream_ptr
+from ._lib import dtype_code, lib, ptr, require_cuda, stream_ptr
 
 
 # ------------------------------------------------------------------------------------------ attention core
@@ -22,8 +22,8 @@ class _XAttnCore(torch.autograd.Function):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         out = torch.empty_like(q)
         lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=q.device)
-        check(lib().mmgl_xattn_fwd(ptr(q), ptr(k), ptr(v), ptr(key_valid), ptr(out), ptr(lse), B, num_heads, T, S, D,
-                                   0.0, 0, 0, dtype_code(q), stream_ptr()), "mmgl_xattn_fwd")
+        _lib.call("mmgl_xattn_fwd", dict(B=B, H=num_heads, T=T, S=S, D=D, esize=q.element_size()), ptr(q), ptr(k), ptr(v), ptr(key_valid), ptr(out), ptr(lse), B, num_heads, T, S, D,
+                                   0.0, 0, 0, dtype_code(q), stream_ptr())
         ctx.save_for_backward(q, k, v, key_valid, lse)
         ctx.num_heads = num_heads
         return out
@@ -39,8 +39,8 @@ class _XAttnCore(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         nbytes = lib().mmgl_xattn_bwd_workspace(B, H, T, S, D)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
-        check(lib().mmgl_xattn_bwd(ptr(dout), ptr(q), ptr(k), ptr(v), ptr(lse), ptr(key_valid), ptr(dq), ptr(dk), ptr(dv),
-                                   ptr(ws), nbytes, B, H, T, S, D, dtype_code(q), stream_ptr()), "mmgl_xattn_bwd")
+        _lib.call("mmgl_xattn_bwd", dict(B=B, H=H, T=T, S=S, D=D, esize=q.element_size()), ptr(dout), ptr(q), ptr(k), ptr(v), ptr(lse), ptr(key_valid), ptr(dq), ptr(dk), ptr(dv),
+                                   ptr(ws), nbytes, B, H, T, S, D, dtype_code(q), stream_ptr())
         return dq, dk, dv, None, None
 
 
@@ -77,8 +77,8 @@ class _LayerNorm(torch.autograd.Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         g = None if gamma is None else gamma.to(x.dtype).contiguous()
         b = None if beta is None else beta.to(x.dtype).contiguous()
-        check(lib().mmgl_layernorm_fwd(ptr(x2), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps,
-                                       dtype_code(x), stream_ptr()), "mmgl_layernorm_fwd")
+        _lib.call("mmgl_layernorm_fwd", dict(bytes=2.0 * rows * cols * x.element_size()), ptr(x2), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps,
+                                       dtype_code(x), stream_ptr())
         ctx.save_for_backward(x2, g, mean, rstd)
         ctx.shape = shape
         ctx.pgrad = (gamma is not None and gamma.requires_grad, beta is not None and beta.requires_grad)
@@ -96,8 +96,8 @@ class _LayerNorm(torch.autograd.Function):
         dbeta = torch.empty(cols, dtype=torch.float32, device=x2.device) if want else None
         nbytes = lib().mmgl_norm_bwd_workspace(rows, cols) if want else 0
         ws = _ws(nbytes, x2.device)
-        check(lib().mmgl_layernorm_bwd(ptr(dy2), ptr(x2), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
-                                       ptr(ws), ws.numel(), rows, cols, dtype_code(x2), stream_ptr()), "mmgl_layernorm_bwd")
+        _lib.call("mmgl_layernorm_bwd", dict(bytes=3.0 * rows * cols * x2.element_size()), ptr(dy2), ptr(x2), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
+                                       ptr(ws), ws.numel(), rows, cols, dtype_code(x2), stream_ptr())
         dg = dgamma.to(ctx.pdtype) if ctx.pgrad[0] else None
         db = dbeta.to(ctx.pdtype) if ctx.pgrad[1] else None
         return dx.view(ctx.shape), dg, db, None
@@ -119,8 +119,7 @@ class _RMSNorm(torch.autograd.Function):
         y = torch.empty_like(x2)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         g = None if gamma is None else gamma.to(x.dtype).contiguous()
-        check(lib().mmgl_rmsnorm_fwd(ptr(x2), ptr(g), ptr(y), ptr(rstd), rows, cols, eps, dtype_code(x), stream_ptr()),
-              "mmgl_rmsnorm_fwd")
+        _lib.call("mmgl_rmsnorm_fwd", None, ptr(x2), ptr(g), ptr(y), ptr(rstd), rows, cols, eps, dtype_code(x), stream_ptr())
         ctx.save_for_backward(x2, g, rstd)
         ctx.shape = shape
         ctx.pgrad = gamma is not None and gamma.requires_grad
@@ -136,8 +135,8 @@ class _RMSNorm(torch.autograd.Function):
         dgamma = torch.empty(cols, dtype=torch.float32, device=x2.device) if ctx.pgrad else None
         nbytes = lib().mmgl_norm_bwd_workspace(rows, cols) if ctx.pgrad else 0
         ws = _ws(nbytes, x2.device)
-        check(lib().mmgl_rmsnorm_bwd(ptr(dy2), ptr(x2), ptr(g), ptr(rstd), ptr(dx), ptr(dgamma), ptr(ws), ws.numel(), rows,
-                                     cols, dtype_code(x2), stream_ptr()), "mmgl_rmsnorm_bwd")
+        _lib.call("mmgl_rmsnorm_bwd", None, ptr(dy2), ptr(x2), ptr(g), ptr(rstd), ptr(dx), ptr(dgamma), ptr(ws), ws.numel(), rows,
+                                     cols, dtype_code(x2), stream_ptr())
         return dx.view(ctx.shape), (dgamma.to(ctx.pdtype) if ctx.pgrad else None), None
 
 
@@ -153,8 +152,8 @@ class _GatedResidual(torch.autograd.Function):
         residual, x = residual.contiguous(), x.contiguous()
         y = torch.empty_like(x)
         g32 = None if gate is None else gate.detach().to(torch.float32).reshape(1).contiguous()
-        check(lib().mmgl_gated_residual_fwd(ptr(residual), ptr(x), ptr(g32), ptr(y), x.numel(), p_drop, seed,
-                                            dtype_code(x), stream_ptr()), "mmgl_gated_residual_fwd")
+        _lib.call("mmgl_gated_residual_fwd", dict(bytes=3.0 * x.numel() * x.element_size()), ptr(residual), ptr(x), ptr(g32), ptr(y), x.numel(), p_drop, seed,
+                                            dtype_code(x), stream_ptr())
         ctx.save_for_backward(x, g32)
         ctx.p, ctx.seed = p_drop, seed
         ctx.gate_meta = None if gate is None else (gate.dtype, gate.shape, gate.requires_grad)
@@ -167,8 +166,8 @@ class _GatedResidual(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgate = torch.zeros(1, dtype=torch.float32, device=x.device) if g32 is not None else None
         ws = _ws(lib().mmgl_gated_residual_bwd_workspace(x.numel()), x.device)
-        check(lib().mmgl_gated_residual_bwd(ptr(dy), ptr(x), ptr(g32), ptr(dx), ptr(dgate), ptr(ws), ws.numel(), x.numel(),
-                                            ctx.p, ctx.seed, dtype_code(x), stream_ptr()), "mmgl_gated_residual_bwd")
+        _lib.call("mmgl_gated_residual_bwd", dict(bytes=3.0 * x.numel() * x.element_size()), ptr(dy), ptr(x), ptr(g32), ptr(dx), ptr(dgate), ptr(ws), ws.numel(), x.numel(),
+                                            ctx.p, ctx.seed, dtype_code(x), stream_ptr())
         dg = None
         if ctx.gate_meta is not None and ctx.gate_meta[2]:
             dg = dgate.to(ctx.gate_meta[0]).reshape(ctx.gate_meta[1])
@@ -197,8 +196,7 @@ class _Linear(torch.autograd.Function):
         w = weight.to(x.dtype).contiguous()
         b = None if bias is None else bias.to(x.dtype).contiguous()
         y = torch.empty(M, N, dtype=x.dtype, device=x.device)
-        check(lib().mmgl_linear_fwd(ptr(x2), ptr(w), ptr(b), ptr(y), M, N, K, act, out_scale, dtype_code(x), stream_ptr()),
-              "mmgl_linear_fwd")
+        _lib.call("mmgl_linear_fwd", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x.element_size()), ptr(x2), ptr(w), ptr(b), ptr(y), M, N, K, act, out_scale, dtype_code(x), stream_ptr())
         ctx.save_for_backward(x2, w, y if act else None)
         ctx.meta = (shape, act, out_scale, weight.dtype, None if bias is None else bias.dtype)
         ctx.need = (x.requires_grad, weight.requires_grad, bias is not None and bias.requires_grad)
@@ -216,15 +214,15 @@ class _Linear(torch.autograd.Function):
         if ctx.need[0]:
             dx = torch.empty_like(x2)
             ws = _ws(lib().mmgl_linear_dgrad_workspace(M, N, K, act, code), x2.device)
-            check(lib().mmgl_linear_dgrad(ptr(dy2), ptr(y), ptr(w), ptr(dx), ptr(ws), ws.numel(), M, N, K, act, out_scale, code,
-                                          stream_ptr()), "mmgl_linear_dgrad")
+            _lib.call("mmgl_linear_dgrad", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x2.element_size()), ptr(dy2), ptr(y), ptr(w), ptr(dx), ptr(ws), ws.numel(), M, N, K, act, out_scale, code,
+                                          stream_ptr())
             dx = dx.view(shape)
         if ctx.need[1] or ctx.need[2]:
             dw = torch.empty_like(w)
             db = torch.empty(N, dtype=x2.dtype, device=x2.device) if ctx.need[2] else None
             ws = _ws(lib().mmgl_linear_wgrad_workspace(M, N, K, code), x2.device)
-            check(lib().mmgl_linear_wgrad(ptr(dy2), ptr(y), ptr(x2), ptr(dw), ptr(db), ptr(ws), ws.numel(), M, N, K, act,
-                                          out_scale, 0, code, stream_ptr()), "mmgl_linear_wgrad")
+            _lib.call("mmgl_linear_wgrad", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x2.element_size()), ptr(dy2), ptr(y), ptr(x2), ptr(dw), ptr(db), ptr(ws), ws.numel(), M, N, K, act,
+                                          out_scale, 0, code, stream_ptr())
             dw = dw.to(wdt) if ctx.need[1] else None
             db = db.to(bdt) if db is not None else None
         return dx, dw, db, None, None
@@ -254,8 +252,8 @@ class _LoraLinear(torch.autograd.Function):
         b = None if bias is None else bias.to(x.dtype).contiguous()
         y = torch.empty(M, N, dtype=x.dtype, device=x.device)
         xa = torch.empty(M, r, dtype=x.dtype, device=x.device)
-        check(lib().mmgl_lora_linear_fwd(ptr(x2), ptr(w), ptr(b), ptr(a), ptr(bm), ptr(y), ptr(xa), M, N, K, r, scale,
-                                         dtype_code(x), stream_ptr()), "mmgl_lora_linear_fwd")
+        _lib.call("mmgl_lora_linear_fwd", None, ptr(x2), ptr(w), ptr(b), ptr(a), ptr(bm), ptr(y), ptr(xa), M, N, K, r, scale,
+                                         dtype_code(x), stream_ptr())
         ctx.save_for_backward(x2, xa, w, a, bm)
         ctx.meta = (shape, scale, A.dtype, Bm.dtype)
         return y.view(*shape[:-1], N)
@@ -271,8 +269,8 @@ class _LoraLinear(torch.autograd.Function):
         dx, dA, dB = torch.empty_like(x2), torch.empty_like(a), torch.empty_like(bm)
         dyb = torch.empty(M, r, dtype=x2.dtype, device=x2.device)
         ws = _ws(lib().mmgl_lora_linear_bwd_workspace(M, N, K, r, code), x2.device)
-        check(lib().mmgl_lora_linear_bwd(ptr(dy2), ptr(x2), ptr(xa), ptr(w), ptr(a), ptr(bm), ptr(dx), ptr(dA), ptr(dB), ptr(dyb),
-                                         ptr(ws), ws.numel(), M, N, K, r, scale, 0, code, stream_ptr()), "mmgl_lora_linear_bwd")
+        _lib.call("mmgl_lora_linear_bwd", None, ptr(dy2), ptr(x2), ptr(xa), ptr(w), ptr(a), ptr(bm), ptr(dx), ptr(dA), ptr(dB), ptr(dyb),
+                                         ptr(ws), ws.numel(), M, N, K, r, scale, 0, code, stream_ptr())
         return dx.view(shape), None, None, dA.to(adt), dB.to(bdt), None
 
 
@@ -295,9 +293,8 @@ class _Interleave(torch.autograd.Function):
         tl, tp = text_loc.contiguous(), text_pos.contiguous()
         il = None if img_loc is None else img_loc.contiguous()
         ip = None if img_pos is None else img_pos.contiguous()
-        check(lib().mmgl_neighbor_interleave_fwd(ptr(text_emb), ptr(vis), ptr(tl), ptr(il), ptr(tp), ptr(ip), ptr(out),
-                                                 ptr(valid), B, Nt, Ni, n_tok, d, dtype_code(text_emb), stream_ptr()),
-              "mmgl_neighbor_interleave_fwd")
+        _lib.call("mmgl_neighbor_interleave_fwd", None, ptr(text_emb), ptr(vis), ptr(tl), ptr(il), ptr(tp), ptr(ip), ptr(out),
+                                                 ptr(valid), B, Nt, Ni, n_tok, d, dtype_code(text_emb), stream_ptr())
         ctx.save_for_backward(tl, il)
         ctx.dims = (B, Nt, Ni, n_tok, d)
         ctx.mark_non_differentiable(valid)
@@ -310,8 +307,8 @@ class _Interleave(torch.autograd.Function):
         dout = dout.contiguous()
         dtext = torch.empty(B, Nt, n_tok, d, dtype=dout.dtype, device=dout.device)
         dvis = torch.empty(B, Ni, n_tok, d, dtype=dout.dtype, device=dout.device) if Ni else None
-        check(lib().mmgl_neighbor_interleave_bwd(ptr(dout), ptr(tl), ptr(il), ptr(dtext), ptr(dvis), B, Nt, Ni, n_tok, d,
-                                                 dtype_code(dout), stream_ptr()), "mmgl_neighbor_interleave_bwd")
+        _lib.call("mmgl_neighbor_interleave_bwd", None, ptr(dout), ptr(tl), ptr(il), ptr(dtext), ptr(dvis), B, Nt, Ni, n_tok, d,
+                                                 dtype_code(dout), stream_ptr())
         return dtext, dvis, None, None, None, None
 
 
@@ -335,8 +332,8 @@ class _CrossEntropy(torch.autograd.Function):
         row_lse = torch.empty(rows, dtype=torch.float32, device=dev)
         row_loss = torch.empty(rows, dtype=torch.float32, device=dev)
         sums = torch.empty(2, dtype=torch.float32, device=dev)
-        check(lib().mmgl_cross_entropy_fwd(ptr(logits), ptr(labels), ptr(row_lse), ptr(row_loss), ptr(sums[0:1]), ptr(sums[1:2]),
-                                           rows, V, ignore_index, dtype_code(logits), stream_ptr()), "mmgl_cross_entropy_fwd")
+        _lib.call("mmgl_cross_entropy_fwd", dict(bytes=1.0 * rows * V * logits.element_size()), ptr(logits), ptr(labels), ptr(row_lse), ptr(row_loss), ptr(sums[0:1]), ptr(sums[1:2]),
+                                           rows, V, ignore_index, dtype_code(logits), stream_ptr())
         ctx.save_for_backward(logits, labels, row_lse, sums)
         ctx.ignore = ignore_index
         return sums[0] / sums[1]
@@ -347,8 +344,8 @@ class _CrossEntropy(torch.autograd.Function):
         rows, V = logits.shape
         dl = dloss.detach().to(torch.float32).reshape(1).contiguous()
         dlogits = torch.empty_like(logits)
-        check(lib().mmgl_cross_entropy_bwd(ptr(logits), ptr(labels), ptr(row_lse), ptr(sums[1:2]), ptr(dl), ptr(dlogits), rows, V,
-                                           ctx.ignore, dtype_code(logits), stream_ptr()), "mmgl_cross_entropy_bwd")
+        _lib.call("mmgl_cross_entropy_bwd", dict(bytes=2.0 * rows * V * logits.element_size()), ptr(logits), ptr(labels), ptr(row_lse), ptr(sums[1:2]), ptr(dl), ptr(dlogits), rows, V,
+                                           ctx.ignore, dtype_code(logits), stream_ptr())
         return dlogits, None, None
 
 
@@ -362,12 +359,12 @@ def position_ids(attention_mask):
     require_cuda(attention_mask)
     m = attention_mask.to(torch.int64).contiguous()
     out = torch.empty_like(m)
-    check(lib().mmgl_position_ids(ptr(m), ptr(out), m.shape[0], m.shape[1], stream_ptr()), "mmgl_position_ids")
+    _lib.call("mmgl_position_ids", None, ptr(m), ptr(out), m.shape[0], m.shape[1], stream_ptr())
     return out
 
 
 def adamw_step_(param, master, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     """In-place fused AdamW over flat buffers (torch.optim.AdamW formula)."""
     require_cuda(param, grad)
-    check(lib().mmgl_adamw_step(ptr(param), ptr(master), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, beta1, beta2,
-                                eps, weight_decay, step, grad_scale, dtype_code(param), stream_ptr()), "mmgl_adamw_step")
+    _lib.call("mmgl_adamw_step", None, ptr(param), ptr(master), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, beta1, beta2,
+                                eps, weight_decay, step, grad_scale, dtype_code(param), stream_ptr())
