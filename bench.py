@@ -120,7 +120,9 @@ def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1):
     """Time the CPU oracle on the same step (frozen encoders fwd, LM fwd+bwd w.r.t. the trainable set) for a bounded
     sample.  fp32, all host cores.  Returns the JSON object for the bench line."""
     from oracle import lm_ref, wrapper_ref
-    cores = os.cpu_count() or 1
+    # threads: torch/MKL fp32 GEMM peaks at ~32 threads on the GPU box's 2 x 64-core EPYC 9575F and collapses beyond
+    # (tools/probes/cpu_threads.py: 1.44 TFLOP/s @32, 0.64 @64, 0.07 @256) -> use min(32, cpu_count)
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     t_build = time.time()
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
@@ -240,7 +242,7 @@ def main():
             "config": {"workload": f"{args.config} context=all neighbor_mode=embedding peft=flamingo, {cfg['nt']}+{cfg['ni']} neighbors x 4 tokens, "
                                    f"T=640, roberta-base + clip-vit-base-patch16 frozen encoders, full train step (fwd+bwd+exchange+AdamW)",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "seq_len": T, "neighbor_keys": (cfg["nt"] + cfg["ni"]) * 4,
-                       "trainable_params": n_train, "parallelism": f"dp{world}", "loss": round(float(loss), 4)},
+                       "trainable_params": n_train, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 4)},
         }
         if timing:
             ks = _lib.KernelTimer.summary()

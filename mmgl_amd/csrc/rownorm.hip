@@ -11,7 +11,7 @@
 namespace {
 
 constexpr int NVMAX = 4;          // 16-B chunks per thread: cols <= 256 * NVMAX * VEC (8192 bf16 / 4096 f32 -> see dispatch)
-constexpr int MAXBLK = 1024;      // backward grid cap (workspace = MAXBLK * cols * 2 floats at most)
+constexpr int MAXBLK = 512;       // backward grid cap: 2 blocks per CU; each block carries its column partials in registers
 
 template <typename T> struct Vec {
     static constexpr int N = 16 / sizeof(T);
@@ -178,18 +178,33 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ dy,
     }
 }
 
-// dgamma[c] = sum_p part[p][c], dbeta[c] = sum_p part[p][cols + c]
+// dgamma[c] = sum_p part[p][c], dbeta[c] = sum_p part[p][cols + c].  A partial row is 2*cols floats.
+// Block = 32 columns x 8 partial-row lanes (8 independent load streams per column instead of one serial chain),
+// folded through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void norm_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, int nparts, int cols) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float a = 0.f, b = 0.f;
-    for (int p = 0; p < nparts; ++p) {
-        a += part[(size_t)p * cols * 2 + c];
-        b += part[(size_t)p * cols * 2 + cols + c];
+    __shared__ float red[8][33];
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;               // column in [0, 2*cols)
+    float a = 0.f;
+    if (c < 2 * cols) {
+        int p = py;
+        for (; p + 24 < nparts; p += 32) {
+            const float v0 = part[(size_t)p * cols * 2 + c], v1 = part[(size_t)(p + 8) * cols * 2 + c];
+            const float v2 = part[(size_t)(p + 16) * cols * 2 + c], v3 = part[(size_t)(p + 24) * cols * 2 + c];
+            a += (v0 + v1) + (v2 + v3);
+        }
+        for (; p < nparts; p += 8) a += part[(size_t)p * cols * 2 + c];
     }
-    if (dgamma) dgamma[c] = a;
-    if (dbeta) dbeta[c] = b;
+    red[py][cx] = a;
+    __syncthreads();
+    if (py == 0 && c < 2 * cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += red[i][cx];
+        if (c < cols) { if (dgamma) dgamma[c] = s; }
+        else if (dbeta) dbeta[c - cols] = s;
+    }
 }
 
 struct Geo { int tpr, nv, rpb; };
@@ -255,7 +270,7 @@ int norm_bwd(const char* who, const void* dy, const void* x, const void* gamma, 
                   (const T*)gamma, mean, rstd, (T*)dx, part, rows, cols);
     MMGL_CHECK_LAUNCH(who);
     if (want) {
-        hipLaunchKernelGGL(norm_param_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, part, dgamma, dbeta,
+        hipLaunchKernelGGL(norm_param_reduce_kernel, dim3((2 * cols + 31) / 32), dim3(256), 0, st, part, dgamma, dbeta,
                            blocks * g.rpb, cols);
         MMGL_CHECK_LAUNCH(who);
     }

@@ -40,7 +40,7 @@ def _grad_ready_order(named_params):
 class DataParallelEngine:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.01, bucket_mb: int = 256, process_group=None, master_weights: Optional[bool] = None,
-                 fused: Optional[bool] = None, broadcast: bool = True):
+                 fused: Optional[bool] = None, broadcast: bool = True, optimizer: str = "adamw"):
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -48,6 +48,7 @@ class DataParallelEngine:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.sync = True
+        self.optimizer_kind = optimizer
 
         named = _grad_ready_order([(n, p) for n, p in model.named_parameters() if p.requires_grad])
         if not named:
@@ -79,11 +80,24 @@ class DataParallelEngine:
             self.flat_param[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.flat_param[o:o + p.numel()].view(p.shape)
             p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
-        if broadcast and self.world > 1:             # DDP's constructor broadcast of parameters (run_generation.py:319)
+        if broadcast and self.world > 1:             # DDP's constructor broadcast of parameters AND buffers (run_generation.py:319)
             dist.broadcast(self.flat_param, src=0, group=self.pg)
+            mine = {id(p) for p in self.params}
+            seen_t = set()
+            for t in list(model.parameters()) + list(model.buffers()):
+                if id(t) in mine or id(t) in seen_t or t.numel() == 0:
+                    continue
+                seen_t.add(id(t))
+                dist.broadcast(t.data, src=0, group=self.pg)      # frozen LM / encoders: one-off, ~3 GB at OPT-1.3B
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.master = self.flat_param.float() if master_weights else None
+        self.torch_optimizer = None
+        if optimizer == "adafactor":          # the reference trains T5 with Adafactor (run_generation.py:321-324)
+            from transformers.optimization import Adafactor
+            self.torch_optimizer = Adafactor(self.params, scale_parameter=False, relative_step=False, warmup_init=False, lr=lr)
+        elif optimizer != "adamw":
+            raise ValueError(f"unknown optimizer {optimizer!r}")
 
         # ---- buckets = contiguous ranges of the flat gradient, closed in grad-ready order
         cap = max(1, bucket_mb * (1 << 20) // self.flat_grad.element_size())
@@ -146,6 +160,13 @@ class DataParallelEngine:
         self.step_count += 1
         scale = 1.0 / self.world
         b1, b2 = self.betas
+        if self.torch_optimizer is not None:
+            if self.world > 1:
+                self.flat_grad.mul_(scale)
+            for g in self.torch_optimizer.param_groups:
+                g["lr"] = lr
+            self.torch_optimizer.step()
+            return
         if self.fused:
             from . import ops
             ops.adamw_step_(self.flat_param, self.master, self.flat_grad, self.exp_avg, self.exp_avg_sq, lr, b1, b2, self.eps,

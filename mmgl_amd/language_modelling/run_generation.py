@@ -96,3 +96,420 @@ class Arguments:
     lora_r: int = _f(64, "lora row rank")
     lora_alpha: float = _f(1, "lora scaling factor")
     lora_dropout: float = _f(0.0, "lora dropout rate")
+
+
+# =============================================================================================== schedule / metrics
+class WarmupStepLR:
+    """lr(step): linear 0 -> base over `warmup` optimizer steps (GradualWarmupScheduler, multiplier 1.0), then StepLR
+    (x gamma every `step_size` steps, counted from the hand-over) -- reference :332-333.  Parity with the third-party
+    warmup_scheduler package is UNPINNED (absent here)."""
+
+    def __init__(self, base_lr, warmup, step_size, gamma):
+        self.base_lr, self.warmup, self.step_size, self.gamma = base_lr, max(int(warmup), 0), max(int(step_size), 1), gamma
+        self.last_step = 0
+
+    def lr_at(self, step):
+        if self.warmup and step <= self.warmup:
+            return self.base_lr * step / self.warmup
+        return self.base_lr * self.gamma ** ((step - self.warmup) // self.step_size)
+
+    def step(self):
+        self.last_step += 1
+        return self.lr_at(self.last_step)
+
+    def get_last_lr(self):
+        return [self.lr_at(self.last_step)]
+
+    def state_dict(self):
+        return dict(last_step=self.last_step, base_lr=self.base_lr, warmup=self.warmup, step_size=self.step_size, gamma=self.gamma)
+
+    def load_state_dict(self, sd):
+        self.last_step = sd.get("last_step", 0)
+
+
+def corpus_bleu(preds, refs, n_gram=4):
+    """Corpus BLEU-n with brevity penalty, uniform weights, whitespace tokens (the quantity torchmetrics.BLEUScore
+    computes; torchmetrics is absent here).  refs: list of lists of reference strings."""
+    import math
+    from collections import Counter
+    num = [0] * n_gram
+    den = [0] * n_gram
+    pred_len = ref_len = 0
+    for p, rs in zip(preds, refs):
+        pt = p.split()
+        rts = [r.split() for r in rs]
+        pred_len += len(pt)
+        ref_len += min((abs(len(r) - len(pt)), len(r)) for r in rts)[1] if rts else 0
+        for k in range(1, n_gram + 1):
+            pc = Counter(tuple(pt[i:i + k]) for i in range(len(pt) - k + 1))
+            mx = Counter()
+            for r in rts:
+                rc = Counter(tuple(r[i:i + k]) for i in range(len(r) - k + 1))
+                for g, c in rc.items():
+                    mx[g] = max(mx[g], c)
+            num[k - 1] += sum(min(c, mx[g]) for g, c in pc.items())
+            den[k - 1] += max(len(pt) - k + 1, 0)
+    if min(num) == 0 or pred_len == 0:
+        return 0.0
+    logp = sum(math.log(nm / dn) for nm, dn in zip(num, den)) / n_gram
+    bp = 1.0 if pred_len > ref_len else math.exp(1 - ref_len / pred_len)
+    return bp * math.exp(logp)
+
+
+# =============================================================================================== model / data factories
+OFFLINE_LM_DIMS = {  # architectures that can be built without a checkpoint (`--dataset synthetic`, benchmarks)
+    "opt-125m": dict(hidden_size=768, num_attention_heads=12, ffn_dim=3072, num_hidden_layers=12, word_embed_proj_dim=768),
+    "opt-350m": dict(hidden_size=1024, num_attention_heads=16, ffn_dim=4096, num_hidden_layers=24, word_embed_proj_dim=512,
+                     do_layer_norm_before=False),
+    "opt-1.3b": dict(hidden_size=2048, num_attention_heads=32, ffn_dim=8192, num_hidden_layers=24, word_embed_proj_dim=2048),
+    "opt-tiny": dict(hidden_size=64, num_attention_heads=4, ffn_dim=128, num_hidden_layers=4, word_embed_proj_dim=64,
+                     max_position_embeddings=256),
+    "t5-small": dict(d_model=512, d_kv=64, d_ff=2048, num_layers=6, num_heads=8),
+    "t5-tiny": dict(d_model=64, d_kv=16, d_ff=128, num_layers=2, num_heads=4),
+}
+
+
+def offline_configs(args, vocab_size):
+    """Random-init HF configs for the named architecture (no network / checkpoints in this environment)."""
+    from transformers import CLIPVisionConfig, OPTConfig, RobertaConfig, T5Config
+    name = args.model_name_or_path.replace("mpt", "opt").split("/")[-1]
+    dims = dict(OFFLINE_LM_DIMS[name])
+    if "t5" in name:
+        lm = T5Config(vocab_size=vocab_size, decoder_start_token_id=1, pad_token_id=1, eos_token_id=2, **dims)
+    else:
+        dims.setdefault("max_position_embeddings", 2048)
+        lm = OPTConfig(vocab_size=vocab_size, pad_token_id=1, bos_token_id=2, eos_token_id=2, **dims)
+    tiny = "tiny" in name
+    txt = RobertaConfig(vocab_size=vocab_size, hidden_size=32 if tiny else 768, num_hidden_layers=2 if tiny else 12,
+                        num_attention_heads=2 if tiny else 12, intermediate_size=64 if tiny else 3072,
+                        max_position_embeddings=args.max_input_length + 2, pad_token_id=1, type_vocab_size=1)
+    vis = CLIPVisionConfig(hidden_size=32 if tiny else 768, intermediate_size=64 if tiny else 3072, num_hidden_layers=2 if tiny else 12,
+                           num_attention_heads=2 if tiny else 12, image_size=getattr(args, "image_size", 224), patch_size=16)
+    return lm, txt, vis
+
+
+def build_model(args, tokenizer, offline=False):
+    """Model dispatch on substrings of model_name_or_path (reference :286-301) -- "t5"/"opt" -> SelfAttentionModel,
+    "mpt" -> CrossAttentionModel on the corresponding OPT; an "opt" name with peft_type flamingo also selects the
+    cross-attention model (README pairing)."""
+    from ..model import CrossAttentionModel, SelfAttentionModel
+    name = args.model_name_or_path
+    cfgs = {}
+    if offline:
+        lm, txt, vis = offline_configs(args, len(tokenizer))
+        cfgs = dict(lm_config=lm, text_config=txt, visual_config=vis)
+    if "t5" in name:
+        args.decoder_only = False
+        return SelfAttentionModel(args, tokenizer, **cfgs)
+    if "mpt" in name or ("opt" in name and args.peft_type == "flamingo"):
+        args.decoder_only = True
+        args.model_name_or_path = name.replace("mpt", "opt")
+        return CrossAttentionModel(args, tokenizer, **cfgs)
+    if "opt" in name:
+        args.decoder_only = True
+        return SelfAttentionModel(args, tokenizer, **cfgs)
+    raise ValueError(f"unsupported model_name_or_path {name!r}: expected a t5 / opt / mpt name (reference :286-301)")
+
+
+def build_datasets(args, tokenizer):
+    from ..wikiweb2m import WikiWeb2M, load_wikiweb2m
+    if args.dataset == "synthetic":
+        from ..wikiweb2m.synthetic import synthetic_id_list, synthetic_pages
+        dfs = [synthetic_pages(24, seed=s) for s in (11, 12, 13)]
+        ids = {k: synthetic_id_list(df) for k, df in zip(("train", "val", "test"), dfs)}
+        vis = None
+    else:
+        train_df, val_df, test_df, ids = load_wikiweb2m(args.task)
+        dfs, vis = [train_df, val_df, test_df], args.visual_model
+    return [WikiWeb2M(args, df, ids[k], tokenizer, vis) for df, k in zip(dfs, ("train", "val", "test"))]
+
+
+# =============================================================================================== loops
+def _device_of(model):
+    return next(model.parameters()).device
+
+
+def _sync(device):
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def _summary_slices(args, logits, labels):
+    """Decoder-only: score only the reference summary, logits[..., L_in:-1] vs labels[..., L_in+1:] (reference :473-478)."""
+    lg = logits[..., args.max_input_length:-1, :]
+    lb = labels[..., (args.max_input_length + 1):]
+    if lg.shape[1] - lb.shape[1] > 0:
+        lg = lg[..., :-(lg.shape[1] - lb.shape[1]), :]
+    return lg, lb
+
+
+def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, run=None):
+    """One epoch (reference :430-524).  `engine` = DataParallelEngine (replaces DDP + optimizer)."""
+    from . import utils
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    device = _device_of(model)
+    batch_time = utils.AverageMeter("Time", ":6.3f")
+    data_time = utils.AverageMeter("Data", ":6.3f")
+    forward_time = utils.AverageMeter("Forward", ":6.3f")
+    losses = utils.AverageMeter("Loss", ":.4e")
+    progress = utils.ProgressMeter(args.steps_per_epoch, [batch_time, losses], prefix=f"Epoch: [{epoch}]")
+    pad_id = tokenizer.pad_token_id if tokenizer is not None else 1
+    accum = max(1, args.grad_accumulation_steps)
+    model.train()
+    engine.zero_grad()
+    history = []
+    _sync(device)
+    end = time.time()
+    for i, batch in enumerate(train_loader):
+        data_time.update(time.time() - end)
+        batch = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
+        boundary = ((i + 1) % accum == 0) or (i == args.steps_per_epoch - 1)
+        engine.sync = boundary                         # gradients cross xGMI once per optimizer step
+        forward_start = time.time()
+        outputs = model(**batch)
+        _sync(device)
+        forward_time.update(time.time() - forward_start)
+        loss = outputs.loss
+        if args.decoder_only:
+            lg, lb = _summary_slices(args, outputs.logits.detach(), batch["labels"])
+            summary_loss = nn.functional.cross_entropy(lg.reshape(-1, lg.size(-1)).float(), lb.reshape(-1), ignore_index=pad_id)
+            losses.update(summary_loss.item(), batch["input_ids"].size(0))
+        else:
+            losses.update(loss.item(), batch["input_ids"].size(0))
+        (loss / accum).backward()
+        engine.finish_backward()
+        if boundary:
+            lr = scheduler.step() if scheduler is not None else None
+            engine.step(lr)
+            # the reference clips only if grad_clip > 2, AFTER the step, i.e. to no effect (:490-493): nothing to do
+            engine.zero_grad()
+            actual_step = (epoch * args.steps_per_epoch + i + 1) // accum
+            if actual_step == 1 or actual_step % args.print_freq == 0:
+                for m in (losses, batch_time, data_time, forward_time):
+                    m.all_reduce()
+                ex_per_sec = (args.per_device_train_batch_size / max(batch_time.avg, 1e-9)) * world_size
+                history.append(dict(step=actual_step, loss=losses.avg, examples_per_sec=ex_per_sec, lr=lr))
+                if rank == 0:
+                    progress.display(i + 1)
+                    print(f"  step {actual_step}: loss {losses.avg:.4f}  examples/sec {ex_per_sec:.2f}  "
+                          f"data {data_time.avg:.3f}s  fwd {forward_time.avg:.3f}s  lr {lr}")
+                for m in (losses, batch_time, data_time, forward_time):
+                    m.reset()
+        _sync(device)
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if i == args.steps_per_epoch - 1:
+            break
+    return history
+
+
+def evaluate_loop(val_loader, model, tokenizer, epoch, args, run=None, prefix="val"):
+    """Teacher-forced evaluation (reference :527-703): argmax tokens on the summary span, all-gathered, decoded,
+    truncated at the first '.', scored with BLEU-1..4 and CIDEr.  Returns BLEU-4 (the model-selection metric, :703)."""
+    from . import utils
+    from ..wikiweb2m.cider import Cider
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    device = _device_of(model)
+    batch_time = utils.AverageMeter("Time", ":6.3f", utils.Summary.AVERAGE)
+    losses = utils.AverageMeter("Loss", ":.4e", utils.Summary.AVERAGE)
+    progress = utils.ProgressMeter(args.val_steps_per_epoch, [batch_time, losses], prefix=f"{prefix}: ")
+    pad_id = tokenizer.pad_token_id
+    model.eval()
+    gen_caps, gt_caps = [], []
+    with torch.no_grad():
+        end = time.time()
+        for i, batch in enumerate(val_loader):
+            batch = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
+            outputs = model(**batch)
+            logits = outputs.logits
+            if args.decoder_only:
+                logits, labels = _summary_slices(args, logits, batch["labels"])
+                loss = nn.functional.cross_entropy(logits.reshape(-1, logits.size(-1)).float(), labels.reshape(-1), ignore_index=pad_id)
+            else:
+                labels, loss = batch["labels"], outputs.loss
+            losses.update(loss.item(), batch["input_ids"].size(0))
+            if prefix == "test" and hasattr(model, "generate"):
+                generated_ids = model.generate(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], max_new_tokens=32)
+            else:
+                generated_ids = torch.argmax(logits, dim=-1)            # the reference's wrappers have no generate() (:600)
+            labels = labels.contiguous()
+            generated_ids = generated_ids.contiguous()
+            if world_size > 1:
+                gl = [torch.zeros_like(generated_ids) for _ in range(world_size)]
+                tl = [torch.zeros_like(labels) for _ in range(world_size)]
+                dist.all_gather(gl, generated_ids)
+                dist.all_gather(tl, labels)
+                generated_ids, labels = torch.cat(gl), torch.cat(tl)
+            if not args.decoder_only:
+                labels = labels.masked_fill(labels == -100, pad_id)
+            preds = tokenizer.batch_decode(generated_ids, skip_special_tokens=True)
+            gts = tokenizer.batch_decode(labels, skip_special_tokens=True)
+            for p, g in zip(preds, gts):
+                stop = p.find(".")
+                gen_caps.append(p[:stop] if stop > 5 else p)
+                gt_caps.append([g])
+            batch_time.update(time.time() - end)
+            end = time.time()
+            if i % args.print_freq == 0 and rank == 0:
+                progress.display(i + 1)
+            if i == args.val_steps_per_epoch - 1:
+                break
+    bleu = [corpus_bleu(gen_caps, gt_caps, n) for n in (1, 2, 3, 4)]
+    cands = {idx: [p] for idx, p in enumerate(gen_caps)}
+    refs = {idx: g for idx, g in enumerate(gt_caps)}
+    cider_score, _ = Cider().compute_score(refs, cands) if gen_caps else (0.0, None)
+    meters = {}
+    for name, val in [("loss", losses.avg), ("bleu1", bleu[0]), ("bleu2", bleu[1]), ("bleu3", bleu[2]), ("bleu4", bleu[3]), ("cider", cider_score)]:
+        m = utils.AverageMeter(name, ":6.4f", utils.Summary.AVERAGE)
+        m.update(val, 1)
+        m.all_reduce()
+        meters[name] = m.avg
+    if rank == 0:
+        print(f"[{prefix}] epoch {epoch}: " + "  ".join(f"{k} {v:.4f}" for k, v in meters.items()) + f"  ({len(gen_caps)} captions)")
+    evaluate_loop.last = meters
+    return meters["bleu4"]
+
+
+# =============================================================================================== main / worker
+best_acc1 = 0
+
+
+def save_checkpoint(path, model, engine, scheduler, epoch, acc1):
+    """Reference layout (:402-416): frozen encoders stripped, keys sorted, `module.` prefix as under DDP."""
+    sd = {"module." + k: v for k, v in model.state_dict().items() if ".text_model" not in "." + k and ".visual_model" not in "." + k}
+    state = {"epoch": epoch, "best_acc1": acc1, "state_dict": OrderedDict(sorted(sd.items())), "optimizer": engine.state_dict()}
+    if scheduler is not None:
+        state["scheduler"] = scheduler.state_dict()
+    torch.save(state, path)
+
+
+def load_checkpoint(path, model, engine, scheduler, map_location):
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ck["state_dict"].items()}
+    model.load_state_dict(sd, strict=False)
+    engine.sync_master_from_params()
+    if "optimizer" in ck:
+        engine.load_state_dict(ck["optimizer"])
+    if scheduler is not None and "scheduler" in ck:
+        scheduler.load_state_dict(ck["scheduler"])
+    return ck
+
+
+def main_worker(gpu, world_size, args, log_dir, run=None, tokenizer=None, offline=None, datasets=None, backend=None):
+    """One process per GPU (reference :269-428)."""
+    global best_acc1
+    from ..distributed import DataParallelEngine
+    use_cuda = torch.cuda.is_available() and backend != "gloo"
+    backend = backend or ("nccl" if use_cuda else "gloo")
+    if not dist.is_initialized():
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29517")
+        kw = dict(device_id=torch.device("cuda", gpu)) if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, world_size=world_size, rank=int(os.environ.get("RANK", gpu)), **kw)
+    offline = (args.dataset == "synthetic") if offline is None else offline
+    if tokenizer is None:
+        if offline:
+            from ..wikiweb2m.synthetic import synthetic_tokenizer
+            tokenizer = synthetic_tokenizer()
+        else:
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(args.model_name_or_path.replace("mpt", "opt"), use_fast=False)
+    model = build_model(args, tokenizer, offline=offline)
+    if args.fp16:
+        model = model.float()
+    elif args.bf16:
+        model = model.bfloat16()
+    device = torch.device("cuda", gpu) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(gpu)
+    model.to(device)
+    from . import utils
+    if dist.get_rank() == 0:
+        _, ntrain, nfrozen = utils.get_params_count(model)
+        print(f"total_params {ntrain + nfrozen}  trainable_params {ntrain}  non_trainable_params {nfrozen}")
+    engine = DataParallelEngine(model, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2), eps=1e-8,
+                                weight_decay=args.weight_decay, optimizer="adafactor" if "t5" in args.model_name_or_path else "adamw",
+                                master_weights=False if "t5" in args.model_name_or_path else None)
+    scheduler = None
+    if "t5" not in args.model_name_or_path:
+        scheduler = WarmupStepLR(args.learning_rate, args.lr_warmup_steps,
+                                 (args.lr_schedule_step_size * args.steps_per_epoch) // max(1, args.grad_accumulation_steps),
+                                 args.lr_schedule_gamma)
+    if args.resume:
+        path = os.path.join(args.log_dir, args.resume, "ckpt.pth.tar")
+        if os.path.isfile(path):
+            ck = load_checkpoint(path, model, engine, scheduler, device)
+            args.start_epoch, best_acc1 = ck["epoch"], ck["best_acc1"]
+            print(f"=> loaded checkpoint '{path}' (epoch {ck['epoch']}, best_acc {ck['best_acc1']})")
+        else:
+            print(f"=> no checkpoint found at '{path}'")
+
+    train_ds, val_ds, test_ds = datasets if datasets is not None else build_datasets(args, tokenizer)
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    samplers = [DistributedSampler(train_ds, drop_last=True), DistributedSampler(val_ds, shuffle=False, drop_last=True),
+                DistributedSampler(test_ds, shuffle=False, drop_last=True)]
+    nw = args.dataloader_num_workers
+    mk = lambda ds, bs, smp: DataLoader(ds, batch_size=bs, shuffle=False, num_workers=nw, prefetch_factor=(10 if nw else None),
+                                        pin_memory=use_cuda, sampler=smp, drop_last=True)
+    train_loader = mk(train_ds, args.per_device_train_batch_size, samplers[0])
+    val_loader = mk(val_ds, args.per_device_val_batch_size, samplers[1])
+    test_loader = mk(test_ds, args.per_device_val_batch_size, samplers[2])
+    if args.test:
+        return evaluate_loop(test_loader, model, tokenizer, args.start_epoch, args, run, "test")
+    results = dict(history=[], val=[])
+    for epoch in range(args.start_epoch, args.epochs):
+        t0 = time.time()
+        if epoch == 0:
+            evaluate_loop(val_loader, model, tokenizer, epoch - 1, args, run)
+        samplers[0].set_epoch(epoch)
+        results["history"] += train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, run)
+        acc1 = evaluate_loop(val_loader, model, tokenizer, epoch, args, run)
+        results["val"].append(dict(evaluate_loop.last))
+        is_best = acc1 > best_acc1
+        best_acc1 = max(acc1, best_acc1)
+        if dist.get_rank() == 0 and (is_best or epoch == 0) and args.save_dir:
+            print("=> save best val model ...", args.save_dir)
+            save_checkpoint(args.save_dir, model, engine, scheduler, epoch, acc1)
+        if dist.get_rank() == 0:
+            print(f"Epoch {epoch} time: {time.time() - t0:.1f}s")
+    results["engine"] = engine
+    results["model"] = model
+    return results
+
+
+def _spawn_entry(gpu, world_size, args, log_dir):
+    os.environ["RANK"] = str(gpu)
+    main_worker(gpu, world_size, args, log_dir)
+
+
+def main():
+    from transformers import HfArgumentParser
+    args = HfArgumentParser((Arguments,)).parse_args_into_dataclasses()[0]
+    i = 0
+    while os.path.exists(os.path.join(args.log_dir, f"{args.wandb_run}_{i}")):
+        i += 1
+    log_dir = os.path.join(args.log_dir, f"{args.wandb_run}_{i}")
+    os.makedirs(log_dir, exist_ok=True)
+    args.save_dir = os.path.join(log_dir, "ckpt.pth.tar")
+    print(f"Logging to {log_dir}.")
+    if args.seed is not None:
+        random.seed(args.seed)
+        torch.manual_seed(args.seed)
+    if "WORLD_SIZE" in os.environ:                      # torchrun: one process per GPU already exists
+        main_worker(int(os.environ.get("LOCAL_RANK", 0)), int(os.environ["WORLD_SIZE"]), args, log_dir)
+    else:
+        n = max(1, torch.cuda.device_count())
+        if n == 1:
+            os.environ.setdefault("RANK", "0")
+            main_worker(0, 1, args, log_dir)
+        else:
+            import torch.multiprocessing as mp
+            mp.spawn(_spawn_entry, nprocs=n, args=(n, args, log_dir))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+"""CPU plumbing test = BASELINE.json configs[0]: T5 section_only neighbor_mode=raw PEFT=none, gloo world_size 1.
+(The reference itself raises on this config because of its "session" typo; the evident intent runs.)"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from mmgl_amd.language_modelling.run_generation import Arguments, WarmupStepLR, corpus_bleu, main_worker
+
+
+def test_t5_section_only_raw_trains_and_checkpoints(tmp_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29533"
+    os.environ["RANK"] = "0"
+    args = Arguments(model_name_or_path="t5-tiny", dataset="synthetic", context="section_only", neighbor_mode="raw", peft_type="none",
+                     max_input_length=32, max_output_length=12, per_device_train_batch_size=2, per_device_val_batch_size=2,
+                     dataloader_num_workers=0, epochs=1, steps_per_epoch=4, val_steps_per_epoch=2, print_freq=1,
+                     grad_accumulation_steps=2, learning_rate=1e-3, log_dir=str(tmp_path), seed=0)
+    args.save_dir = str(tmp_path / "ckpt.pth.tar")
+    torch.manual_seed(0)
+    try:
+        res = main_worker(0, 1, args, str(tmp_path), backend="gloo")
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    assert args.decoder_only is False
+    hist = res["history"]
+    assert len(hist) == 2 and all(torch.isfinite(torch.tensor(h["loss"])) for h in hist)     # 4 micro-steps / accum 2
+    assert all(h["examples_per_sec"] > 0 for h in hist)
+    val = res["val"][0]
+    assert set(val) == {"loss", "bleu1", "bleu2", "bleu3", "bleu4", "cider"} and val["cider"] >= 0
+    ck = torch.load(args.save_dir, weights_only=False)
+    assert set(ck) == {"epoch", "best_acc1", "state_dict", "optimizer"}             # T5 has no scheduler (reference :324)
+    assert all(k.startswith("module.") for k in ck["state_dict"])
+    assert not any(".text_model" in k or ".visual_model" in k for k in ck["state_dict"])
+
+
+def test_schedule_and_bleu():
+    s = WarmupStepLR(1e-3, 4, 3, 0.1)
+    lrs = [s.step() for _ in range(11)]
+    assert abs(lrs[0] - 2.5e-4) < 1e-12 and abs(lrs[3] - 1e-3) < 1e-12       # linear warm-up
+    assert abs(lrs[4] - 1e-3) < 1e-12 and abs(lrs[6] - 1e-4) < 1e-12 and abs(lrs[9] - 1e-5) < 1e-12
+    assert corpus_bleu(["a b c d e"], [["a b c d e"]]) == 1.0
+    assert corpus_bleu(["x y z"], [["a b c d e"]]) == 0.0
+    assert 0 < corpus_bleu(["the cat sat on a mat today"], [["the cat sat on the mat"]], 2) < 1
+
+
+def test_arguments_surface_matches_reference_defaults():
+    a = Arguments(model_name_or_path="facebook/opt-350m")
+    want = dict(context="section_only", max_input_length=512, max_output_length=128, per_device_train_batch_size=4,
+                grad_accumulation_steps=4, grad_clip=1.0, learning_rate=0.001, adam_beta2=0.95, weight_decay=0.01, lr_warmup_steps=2000,
+                text_model="roberta-base", visual_model="openai/clip-vit-base-patch16", n_text_tokens=4, n_visual_tokens=4,
+                neighbor_mode="raw", max_text_neighbors=11, max_image_neighbors=5, position_type="none", num_neighbor_layers=4,
+                peft_type="none", lora_r=64, lora_alpha=1, lora_dropout=0.0, steps_per_epoch=2000, epochs=90)
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    from transformers import HfArgumentParser
+    parsed = HfArgumentParser((Arguments,)).parse_args_into_dataclasses(
+        ["--model_name_or_path", "facebook/mpt-1.3b", "--peft_type", "flamingo", "--neighbor_mode", "embedding", "--context", "all", "--bf16", "True"])[0]
+    assert parsed.peft_type == "flamingo" and parsed.bf16 is True and parsed.neighbor_layer_wise is None
