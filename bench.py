@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=1)
+    ap.add_argument("--cpu-samples", type=int, default=2)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _sa_args(**kw):
-    return mpt_args(neighbor_mode="embedding", peft_type="none", **kw)
+    base = dict(neighbor_mode="embedding", peft_type="none")
+    base.update(kw)
+    return mpt_args(**base)
 
 
 @pytest.mark.parametrize("tag", ["none", "laplacian"])
