@@ -22,6 +22,7 @@
 // Both are "fragment linear": a fragment read is one conflict-free ds_read_b128 per lane.
 // fp32 activations skip the t image (LDS budget) and gather it from the row image with scalar reads.
 #include "common.h"
+#include <stdlib.h>
 
 #ifndef MMGL_XATTN_HOIST_MAX
 #define MMGL_XATTN_HOIST_MAX 16
@@ -47,6 +48,11 @@ template <typename T, int D_, int NSB_, int WORK_ = 1> struct XC {
     static constexpr bool HOIST = (WORK_ * NSB_ * (D_ / 16) * (int)(sizeof(T) / 2) <= MMGL_XATTN_HOIST_MAX);
     static constexpr int ROWIMG = SPAD * DPAD;       // elements
     static constexpr int TIMGSZ = D * SPAD;          // elements
+    // row-major padded image (bf16): row stride = 2*DPAD + 32 bytes, so the 8 rows two 16-lane groups touch in one
+    // ds_read_b64_tr_b16 cycle fall on 8 distinct 32-byte bank slots (conflict free), and a row-fragment ds_read_b128
+    // is at most 2-way conflicted.
+    static constexpr int LD = DPAD + 16;
+    static constexpr int RMIMG = SPAD * LD;
 };
 
 template <typename C> __device__ __forceinline__ int rf_idx(int sb, int dc, int lane) {
@@ -103,6 +109,37 @@ __device__ __forceinline__ typename Elem<T>::v8 load_tfrag(const T* timg, const 
     }
 }
 
+// Row-major padded image: X[s][0..DPAD) at img + s*LD.
+template <typename T, typename C>
+__device__ __forceinline__ void stage_rowmajor_image(T* img, const T* base, int row_stride, int S) {
+    typedef typename Elem<T>::v8 v8;
+    for (int i = threadIdx.x; i < C::SPAD * C::CPR; i += blockDim.x) {
+        const int s = i / C::CPR, c = i % C::CPR;
+        v8 val = vzero<v8>();
+        if (s < S && c * 8 < C::D) val = *(const v8*)(base + (size_t)s * row_stride + c * 8);
+        *(v8*)(img + s * C::LD + c * 8) = val;
+    }
+}
+// A-operand row fragment (sb, dc) out of a row-major image.
+template <typename T, typename C>
+__device__ __forceinline__ typename Elem<T>::v8 rm_rowfrag(const T* img, int sb, int dc, int lane) {
+    return *(const typename Elem<T>::v8*)(img + (sb * 16 + (lane & 15)) * C::LD + dc * 32 + (lane >> 4) * 8);
+}
+// Transposed fragment (db, ks) out of a row-major bf16 image with the LDS transpose read (ds_read_b64_tr_b16):
+// in each 16-lane group, lane i supplies the address of 4 consecutive channels of key row 4g + (i>>2); the hardware
+// hands lane x the 4 keys of channel x.  Two reads (keys +0, +16) give exactly the key order the score accumulator
+// uses (s = 16(2ks + (e>>2)) + 4g + (e&3)), so no dedicated transposed image has to be built.
+template <typename C>
+__device__ __forceinline__ bf16x8 rm_tfrag_tr16(const bf16* img, int db, int ks, int lane) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int i = lane & 15, g = lane >> 4;
+    const bf16* p = img + (ks * 32 + 4 * g + (i >> 2)) * C::LD + db * 16 + (i & 3) * 4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * C::LD));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+
 template <typename T, typename C>
 __device__ __forceinline__ typename Elem<T>::v8 load_qfrag(const T* base, int t, int T_, size_t row_stride, int dcol) {
     typedef typename Elem<T>::v8 v8;
@@ -137,49 +174,66 @@ __device__ __forceinline__ bool bit64(uint32_t lo, uint32_t hi, int i) {
 }
 
 // ============================================================================================ forward
+// LDS: K as a fragment-linear row image; V as a row-major padded image read through ds_read_b64_tr_b16 (bf16) or as a
+// second row image gathered with scalar reads (fp32).  A workgroup covers `rows_per_wg` query rows of one (b, h); its 4
+// waves take 16*QT-row tiles round-robin, and each wave issues the NEXT tile's Q loads before it computes the current
+// one, so every wave keeps HBM requests in flight across its MFMA / softmax / store phases.
 template <typename T, int D, int NSB>
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                         const T* __restrict__ v, const uint8_t* __restrict__ valid,
                                                         T* __restrict__ out, float* __restrict__ lse, int B, int H,
-                                                        int T_, int S, int rows_per_wave, int nchunk) {
+                                                        int T_, int S, int rows_per_wg, int nchunk) {
     typedef XC<T, D, NSB> C;
     typedef typename Elem<T>::v8 v8;
+    constexpr int TILE = 16 * C::QT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Kf = (T*)smem;
-    T* Vt = Kf + C::ROWIMG;                                   // t image (bf16) or row image (f32)
-    uint8_t* vld = (uint8_t*)(Vt + (C::TIMG ? C::TIMGSZ : C::ROWIMG));
+    T* Vi = Kf + C::ROWIMG;                                   // row-major image (bf16) or row image (f32)
+    uint8_t* vld = (uint8_t*)(Vi + (C::TIMG ? C::RMIMG : C::ROWIMG));
 
     const int vid = xcd_remap(blockIdx.x, B * H * nchunk);
     const int bh = vid / nchunk, chunk = vid % nchunk;
     const int b = bh / H, h = bh % H;
     const size_t HD = (size_t)H * D;
-
-    stage_row_image<T, C>(Kf, k + (size_t)b * S * HD + h * D, HD, S);
-    if constexpr (C::TIMG) stage_t_image<T, C>(Vt, v + (size_t)b * S * HD + h * D, HD, S);
-    else stage_row_image<T, C>(Vt, v + (size_t)b * S * HD + h * D, HD, S);
-    for (int i = threadIdx.x; i < C::SPAD; i += blockDim.x) vld[i] = (i < S) ? valid[(size_t)b * S + i] : 0;
-    __syncthreads();
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = lane & 15, g = lane >> 4;
-    uint32_t vlo, vhi, elo, ehi;
-    lane_key_bits<C>(vld, g, S, vlo, vhi, elo, ehi);
-    const bool any_valid = __ballot((vlo | vhi) != 0) != 0ull;
 
-    const int row_begin = chunk * 4 * rows_per_wave + wave * rows_per_wave;
-    const int row_end = min(row_begin + rows_per_wave, T_);
+    const int wg_begin = chunk * rows_per_wg;
+    const int wg_end = min(wg_begin + rows_per_wg, T_);
     const T* qb = q + (size_t)b * T_ * HD + h * D;
     T* ob = out + (size_t)b * T_ * HD + h * D;
     float* lb = lse + (size_t)bh * T_;
 
-    for (int t0 = row_begin; t0 < row_end; t0 += 16 * C::QT) {
+    // first tile's Q goes out before the K/V staging so its latency overlaps the LDS fill
+    int t0 = wg_begin + wave * TILE;
+    v8 qn[C::QT][C::NDC];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+        for (int dc = 0; dc < C::NDC; ++dc)
+            qn[qt][dc] = load_qfrag<T, C>(qb, (t0 < wg_end) ? t0 + qt * 16 + x : T_, T_, HD, dc * 32 + g * 8);
+
+    stage_row_image<T, C>(Kf, k + (size_t)b * S * HD + h * D, HD, S);
+    if constexpr (C::TIMG) stage_rowmajor_image<T, C>(Vi, v + (size_t)b * S * HD + h * D, HD, S);
+    else stage_row_image<T, C>(Vi, v + (size_t)b * S * HD + h * D, HD, S);
+    for (int i = threadIdx.x; i < C::SPAD; i += blockDim.x) vld[i] = (i < S) ? valid[(size_t)b * S + i] : 0;
+    __syncthreads();
+
+    uint32_t vlo, vhi, elo, ehi;
+    lane_key_bits<C>(vld, g, S, vlo, vhi, elo, ehi);
+    const bool any_valid = __ballot((vlo | vhi) != 0) != 0ull;
+
+    for (; t0 < wg_end; t0 += 4 * TILE) {
         if constexpr (!C::HOIST) asm volatile("" ::: "memory");
         v8 qf[C::QT][C::NDC];
+        const int tn = t0 + 4 * TILE;
 #pragma unroll
         for (int qt = 0; qt < C::QT; ++qt)
 #pragma unroll
-            for (int dc = 0; dc < C::NDC; ++dc)
-                qf[qt][dc] = load_qfrag<T, C>(qb, t0 + qt * 16 + x, T_, HD, dc * 32 + g * 8);
+            for (int dc = 0; dc < C::NDC; ++dc) {
+                qf[qt][dc] = qn[qt][dc];
+                qn[qt][dc] = load_qfrag<T, C>(qb, (tn < wg_end) ? tn + qt * 16 + x : T_, T_, HD, dc * 32 + g * 8);
+            }
 
         f32x4 sacc[C::QT][C::NSB];
 #pragma unroll
@@ -241,7 +295,9 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
             for (int qt = 0; qt < C::QT; ++qt) oacc[qt][db] = vzero<f32x4>();
 #pragma unroll
             for (int ks = 0; ks < C::NKS; ++ks) {
-                const v8 vt = load_tfrag<T, C>(Vt, Vt, db, ks, lane);
+                v8 vt;
+                if constexpr (C::TIMG) vt = rm_tfrag_tr16<C>(Vi, db, ks, lane);
+                else vt = load_tfrag<T, C>(Vi, Vi, db, ks, lane);
 #pragma unroll
                 for (int qt = 0; qt < C::QT; ++qt) mma16(oacc[qt][db], vt, pf[qt][ks]);
             }
@@ -262,59 +318,76 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
 // ============================================================================================ backward 1: dQ (+ row dots)
 // Same streaming structure as forward.  P is recomputed from the saved LSE; delta_t = sum_s P dP (== dO.O, so O is
 // never re-read); dS = P (dP - delta); dQ^T = K^T dS^T.  delta is written for the dK/dV kernel.
+// LDS (bf16): K row-major padded (row fragments for S^T AND tr16 fragments for K^T), V fragment-linear row image.
+// LDS (fp32): K, V row images; K^T gathered with scalar reads.
 template <typename T, int D, int NSB>
 __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const T* __restrict__ dout, const T* __restrict__ q,
                                                            const T* __restrict__ k, const T* __restrict__ v,
                                                            const float* __restrict__ lse, const uint8_t* __restrict__ valid,
                                                            T* __restrict__ dq, float* __restrict__ delta, int B, int H,
-                                                           int T_, int S, int rows_per_wave, int nchunk) {
+                                                           int T_, int S, int rows_per_wg, int nchunk) {
     typedef XC<T, D, NSB, 2> C;
     typedef typename Elem<T>::v8 v8;
+    constexpr int TILE = 16 * C::QT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Kf = (T*)smem;
-    T* Vf = Kf + C::ROWIMG;
-    T* Kt = Vf + C::ROWIMG;                                   // only when TIMG
-    uint8_t* vld = (uint8_t*)(Kt + (C::TIMG ? C::TIMGSZ : 0));
+    T* Ki = (T*)smem;                                          // row-major (bf16) / row image (f32)
+    T* Vf = Ki + (C::TIMG ? C::RMIMG : C::ROWIMG);
+    uint8_t* vld = (uint8_t*)(Vf + C::ROWIMG);
 
     const int vid = xcd_remap(blockIdx.x, B * H * nchunk);
     const int bh = vid / nchunk, chunk = vid % nchunk;
     const int b = bh / H, h = bh % H;
     const size_t HD = (size_t)H * D;
-
-    stage_row_image<T, C>(Kf, k + (size_t)b * S * HD + h * D, HD, S);
-    stage_row_image<T, C>(Vf, v + (size_t)b * S * HD + h * D, HD, S);
-    if constexpr (C::TIMG) stage_t_image<T, C>(Kt, k + (size_t)b * S * HD + h * D, HD, S);
-    for (int i = threadIdx.x; i < C::SPAD; i += blockDim.x) vld[i] = (i < S) ? valid[(size_t)b * S + i] : 0;
-    __syncthreads();
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = lane & 15, g = lane >> 4;
-    uint32_t vlo, vhi, elo, ehi;
-    lane_key_bits<C>(vld, g, S, vlo, vhi, elo, ehi);
-    const bool any_valid = __ballot((vlo | vhi) != 0) != 0ull;
-    const float uni = 1.f / (float)S;
-    const float tie = any_valid ? 1.f : 0.5f;                 // autograd's 50/50 split at the torch.max tie
 
-    const int row_begin = chunk * 4 * rows_per_wave + wave * rows_per_wave;
-    const int row_end = min(row_begin + rows_per_wave, T_);
+    const int wg_begin = chunk * rows_per_wg;
+    const int wg_end = min(wg_begin + rows_per_wg, T_);
     const T* qb = q + (size_t)b * T_ * HD + h * D;
     const T* gb = dout + (size_t)b * T_ * HD + h * D;
     T* dqb = dq + (size_t)b * T_ * HD + h * D;
     const float* lb = lse + (size_t)bh * T_;
     float* db_ = delta + (size_t)bh * T_;
 
-    for (int t0 = row_begin; t0 < row_end; t0 += 16 * C::QT) {
+    int t0 = wg_begin + wave * TILE;
+    v8 qn[C::QT][C::NDC], gn[C::QT][C::NDC];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+        for (int dc = 0; dc < C::NDC; ++dc) {
+            const int t = (t0 < wg_end) ? t0 + qt * 16 + x : T_;
+            qn[qt][dc] = load_qfrag<T, C>(qb, t, T_, HD, dc * 32 + g * 8);
+            gn[qt][dc] = load_qfrag<T, C>(gb, t, T_, HD, dc * 32 + g * 8);
+        }
+
+    if constexpr (C::TIMG) stage_rowmajor_image<T, C>(Ki, k + (size_t)b * S * HD + h * D, HD, S);
+    else stage_row_image<T, C>(Ki, k + (size_t)b * S * HD + h * D, HD, S);
+    stage_row_image<T, C>(Vf, v + (size_t)b * S * HD + h * D, HD, S);
+    for (int i = threadIdx.x; i < C::SPAD; i += blockDim.x) vld[i] = (i < S) ? valid[(size_t)b * S + i] : 0;
+    __syncthreads();
+
+    uint32_t vlo, vhi, elo, ehi;
+    lane_key_bits<C>(vld, g, S, vlo, vhi, elo, ehi);
+    const bool any_valid = __ballot((vlo | vhi) != 0) != 0ull;
+    const float uni = 1.f / (float)S;
+    const float tie = any_valid ? 1.f : 0.5f;                 // autograd's 50/50 split at the torch.max tie
+
+    for (; t0 < wg_end; t0 += 4 * TILE) {
         if constexpr (!C::HOIST) asm volatile("" ::: "memory");
         v8 qf[C::QT][C::NDC], gf[C::QT][C::NDC];
         float lset[C::QT];
+        const int tn = t0 + 4 * TILE;
 #pragma unroll
         for (int qt = 0; qt < C::QT; ++qt) {
             const int t = t0 + qt * 16 + x;
             lset[qt] = (t < T_) ? lb[t] : 0.f;
+            const int tp = (tn < wg_end) ? tn + qt * 16 + x : T_;
 #pragma unroll
             for (int dc = 0; dc < C::NDC; ++dc) {
-                qf[qt][dc] = load_qfrag<T, C>(qb, t, T_, HD, dc * 32 + g * 8);
-                gf[qt][dc] = load_qfrag<T, C>(gb, t, T_, HD, dc * 32 + g * 8);
+                qf[qt][dc] = qn[qt][dc];
+                gf[qt][dc] = gn[qt][dc];
+                qn[qt][dc] = load_qfrag<T, C>(qb, tp, T_, HD, dc * 32 + g * 8);
+                gn[qt][dc] = load_qfrag<T, C>(gb, tp, T_, HD, dc * 32 + g * 8);
             }
         }
         v8 dsf[C::QT][C::NKS];
@@ -327,7 +400,9 @@ __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const T* __restrict__
                 for (int qt = 0; qt < C::QT; ++qt) { sacc[qt][sb] = vzero<f32x4>(); pacc[qt][sb] = vzero<f32x4>(); }
 #pragma unroll
                 for (int dc = 0; dc < C::NDC; ++dc) {
-                    const v8 kf = *(const v8*)(Kf + rf_idx<C>(sb, dc, lane));
+                    v8 kf;
+                    if constexpr (C::TIMG) kf = rm_rowfrag<T, C>(Ki, sb, dc, lane);
+                    else kf = *(const v8*)(Ki + rf_idx<C>(sb, dc, lane));
                     const v8 vf = *(const v8*)(Vf + rf_idx<C>(sb, dc, lane));
 #pragma unroll
                     for (int qt = 0; qt < C::QT; ++qt) {
@@ -367,7 +442,9 @@ __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const T* __restrict__
             for (int qt = 0; qt < C::QT; ++qt) acc[qt][db] = vzero<f32x4>();
 #pragma unroll
             for (int ks = 0; ks < C::NKS; ++ks) {
-                const v8 kt = load_tfrag<T, C>(Kt, Kf, db, ks, lane);
+                v8 kt;
+                if constexpr (C::TIMG) kt = rm_tfrag_tr16<C>(Ki, db, ks, lane);
+                else kt = load_tfrag<T, C>(Ki, Ki, db, ks, lane);
 #pragma unroll
                 for (int qt = 0; qt < C::QT; ++qt) mma16(acc[qt][db], kt, dsf[qt][ks]);
             }
@@ -557,15 +634,23 @@ BwdPlan bwd_plan(int B, int H, int T, int S, int D) {
     return p;
 }
 
-void fwd_geometry(int B, int H, int T, int qt_rows, int& rows_per_wave, int& nchunk) {
-    // aim for >= ~1024 workgroups (4 per CU) while keeping >= one iteration per wave
-    int bh = B * H;
-    int want = (1024 + bh - 1) / bh;
-    int rpw = (T + 4 * want - 1) / (4 * want);
-    rpw = (rpw + qt_rows - 1) / qt_rows * qt_rows;
-    if (rpw < qt_rows) rpw = qt_rows;
-    rows_per_wave = rpw;
-    nchunk = (T + 4 * rpw - 1) / (4 * rpw);
+int tune_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// rows_per_wg / nchunk: about `target` workgroups in flight (all resident in one round: 2-5 per CU), each workgroup a
+// whole number of 4-wave tile rounds where possible.
+void fwd_geometry(int B, int H, int T, int tile_rows, int& rows_per_wg, int& nchunk) {
+    static const int target = tune_env("MMGL_XATTN_TARGET_WGS", 768);
+    const int bh = B * H;
+    int nc = (target + bh / 2) / bh;
+    const int maxc = (T + tile_rows - 1) / tile_rows;
+    if (nc > maxc) nc = maxc;
+    if (nc < 1) nc = 1;
+    int rows = ((T + nc - 1) / nc + tile_rows - 1) / tile_rows * tile_rows;
+    rows_per_wg = rows;
+    nchunk = (T + rows - 1) / rows;
 }
 
 template <typename K> int set_lds(K kern, size_t bytes) {
@@ -583,7 +668,7 @@ int launch_fwd(const void* q, const void* k, const void* v, const uint8_t* valid
     typedef XC<T, D, NSB> C;
     int rpw, nchunk;
     fwd_geometry(B, H, T_, 16 * C::QT, rpw, nchunk);
-    size_t lds = sizeof(T) * (C::ROWIMG + (C::TIMG ? C::TIMGSZ : C::ROWIMG)) + C::SPAD;
+    size_t lds = sizeof(T) * (C::ROWIMG + (C::TIMG ? C::RMIMG : C::ROWIMG)) + C::SPAD;
     auto kern = xattn_fwd_kernel<T, D, NSB>;
     int rc = set_lds(kern, lds);
     if (rc) return rc;
@@ -604,7 +689,7 @@ int launch_bwd(const void* dout, const void* q, const void* k, const void* v, co
     {
         int rpw, nchunk;
         fwd_geometry(B, H, T_, 16 * C::QT, rpw, nchunk);
-        size_t lds = sizeof(T) * (2 * C::ROWIMG + (C::TIMG ? C::TIMGSZ : 0)) + C::SPAD;
+        size_t lds = sizeof(T) * (C::ROWIMG + (C::TIMG ? C::RMIMG : C::ROWIMG)) + C::SPAD;
         auto kern = xattn_bwd_dq_kernel<T, D, NSB>;
         int rc = set_lds(kern, lds);
         if (rc) return rc;
