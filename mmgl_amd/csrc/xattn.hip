@@ -173,6 +173,76 @@ __device__ __forceinline__ bool bit64(uint32_t lo, uint32_t hi, int i) {
     return i < 32 ? ((lo >> i) & 1u) : ((hi >> (i - 32)) & 1u);
 }
 
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define OOB 0xFFFFFFF0u          // byte offset past any descriptor range: loads return 0, stores are dropped
+
+// Hardware-bounds-checked buffer access: rows past T (and the zero-padded channels of D = 16) need no branches, so the
+// compiler sees every VMEM op of the loop and can wait with exact vmcnt counts (loads of the NEXT tile stay in flight
+// behind this tile's stores instead of draining at vmcnt(0) every iteration).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+template <typename T> __device__ __forceinline__ typename Elem<T>::v8 buf_load8(__amdgpu_buffer_rsrc_t r, uint32_t off);
+template <> __device__ __forceinline__ bf16x8 buf_load8<bf16>(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+template <> __device__ __forceinline__ f32x8 buf_load8<float>(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 0));
+    f32x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return v;
+}
+template <typename T> __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, uint32_t off, const f32x4& v);
+template <> __device__ __forceinline__ void buf_store4<bf16>(__amdgpu_buffer_rsrc_t r, uint32_t off, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4)), r, off, 0, 0);
+}
+template <> __device__ __forceinline__ void buf_store4<float>(__amdgpu_buffer_rsrc_t r, uint32_t off, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+template <typename T> __device__ __forceinline__ typename Elem<T>::v4 cvt4(const f32x4& v);
+template <> __device__ __forceinline__ f32x4 cvt4<float>(const f32x4& v) { return v; }
+template <> __device__ __forceinline__ bf16x4 cvt4<bf16>(const f32x4& v) { return __builtin_convertvector(v, bf16x4); }
+template <typename T> __device__ __forceinline__ void buf_store_v4(__amdgpu_buffer_rsrc_t r, uint32_t off, const typename Elem<T>::v4& v);
+template <> __device__ __forceinline__ void buf_store_v4<bf16>(__amdgpu_buffer_rsrc_t r, uint32_t off, const bf16x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0, 0);
+}
+template <> __device__ __forceinline__ void buf_store_v4<float>(__amdgpu_buffer_rsrc_t r, uint32_t off, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+// byte offset of (row t, channel dcol) in a [T, H*D] slab whose descriptor starts at (b, 0, h*D); OOB for padding channels
+template <typename T, typename C> __device__ __forceinline__ uint32_t row_off(int t, uint32_t row_bytes, int dcol) {
+    uint32_t o = (uint32_t)t * row_bytes + (uint32_t)dcol * (uint32_t)sizeof(T);
+    if constexpr (C::D != C::DPAD) o = (dcol < C::D) ? o : OOB;
+    return o;
+}
+
+// reductions across the four 16-lane groups that share a query row: v_permlane16_swap / v_permlane32_swap are plain
+// VALU ops (no LDS round trip like ds_bpermute): swap(v, v) leaves {lower, upper} halves side by side in the two results.
+__device__ __forceinline__ float xg_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    v = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
+}
+__device__ __forceinline__ float xg_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    v = __builtin_bit_cast(float, a[0]) + __builtin_bit_cast(float, a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return __builtin_bit_cast(float, b[0]) + __builtin_bit_cast(float, b[1]);
+}
+// additive key mask in accumulator layout: 0 for a valid key, -inf otherwise.  Used as the MFMA C-input, so masked
+// scores cost no instruction in the loop (exp2(-inf) = 0 drops them from the softmax sum as well).
+template <typename C> __device__ __forceinline__ void key_bias(uint32_t vlo, uint32_t vhi, f32x4 (&bias)[C::NSB]) {
+#pragma unroll
+    for (int sb = 0; sb < C::NSB; ++sb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[sb][r] = bit64(vlo, vhi, sb * 4 + r) ? 0.f : -INFINITY;
+}
+
 // ============================================================================================ forward
 // LDS: K as a fragment-linear row image; V as a row-major padded image read through ds_read_b64_tr_b16 (bf16) or as a
 // second row image gathered with scalar reads (fp32).  A workgroup covers `rows_per_wg` query rows of one (b, h); its 4
@@ -200,9 +270,11 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
 
     const int wg_begin = chunk * rows_per_wg;
     const int wg_end = min(wg_begin + rows_per_wg, T_);
-    const T* qb = q + (size_t)b * T_ * HD + h * D;
-    T* ob = out + (size_t)b * T_ * HD + h * D;
-    float* lb = lse + (size_t)bh * T_;
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t slab = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
 
     // first tile's Q goes out before the K/V staging so its latency overlaps the LDS fill
     int t0 = wg_begin + wave * TILE;
@@ -211,7 +283,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
     for (int qt = 0; qt < C::QT; ++qt)
 #pragma unroll
         for (int dc = 0; dc < C::NDC; ++dc)
-            qn[qt][dc] = load_qfrag<T, C>(qb, (t0 < wg_end) ? t0 + qt * 16 + x : T_, T_, HD, dc * 32 + g * 8);
+            qn[qt][dc] = buf_load8<T>(rq, row_off<T, C>((t0 < wg_end) ? t0 + qt * 16 + x : T_, row_bytes, dc * 32 + g * 8));
 
     stage_row_image<T, C>(Kf, k + (size_t)b * S * HD + h * D, HD, S);
     if constexpr (C::TIMG) stage_rowmajor_image<T, C>(Vi, v + (size_t)b * S * HD + h * D, HD, S);
@@ -222,7 +294,23 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
     uint32_t vlo, vhi, elo, ehi;
     lane_key_bits<C>(vld, g, S, vlo, vhi, elo, ehi);
     const bool any_valid = __ballot((vlo | vhi) != 0) != 0ull;
+    f32x4 bias[C::NSB];
+    key_bias<C>(vlo, vhi, bias);
 
+    // Software pipeline (per wave, in VMEM issue order):  stores(i-1), loads(i+1), compute(i).
+    // vmcnt is an in-order counter shared by loads and stores, so the wait for tile i's loads also waits for every
+    // older store; issuing a tile's stores one compute phase late (right before the next loads) means both have had a
+    // whole MFMA/softmax phase to complete and the wait is free, instead of a store round trip per iteration.
+    typedef typename Elem<T>::v4 v4;
+    v4 ost[C::QT][C::NDB];
+    float lst[C::QT];
+    int tprev = T_;                       // row index past the slab: the first round's stores are dropped by the bounds check
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        lst[qt] = 0.f;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) ost[qt][db] = vzero<v4>();
+    }
     for (; t0 < wg_end; t0 += 4 * TILE) {
         if constexpr (!C::HOIST) asm volatile("" ::: "memory");
         v8 qf[C::QT][C::NDC];
@@ -230,16 +318,26 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
 #pragma unroll
         for (int qt = 0; qt < C::QT; ++qt)
 #pragma unroll
-            for (int dc = 0; dc < C::NDC; ++dc) {
-                qf[qt][dc] = qn[qt][dc];
-                qn[qt][dc] = load_qfrag<T, C>(qb, (tn < wg_end) ? tn + qt * 16 + x : T_, T_, HD, dc * 32 + g * 8);
-            }
+            for (int dc = 0; dc < C::NDC; ++dc) qf[qt][dc] = qn[qt][dc];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            const int t = tprev + qt * 16 + x;
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db) buf_store_v4<T>(ro, row_off<T, C>(t, row_bytes, db * 16 + g * 4), ost[qt][db]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, lst[qt]), rl, (g == 0) ? (uint32_t)t * 4u : OOB, 0, 0);
+        }
+        tprev = t0;
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc)
+                qn[qt][dc] = buf_load8<T>(rq, row_off<T, C>((tn < wg_end) ? tn + qt * 16 + x : T_, row_bytes, dc * 32 + g * 8));
 
         f32x4 sacc[C::QT][C::NSB];
 #pragma unroll
         for (int sb = 0; sb < C::NSB; ++sb) {
 #pragma unroll
-            for (int qt = 0; qt < C::QT; ++qt) sacc[qt][sb] = vzero<f32x4>();
+            for (int qt = 0; qt < C::QT; ++qt) sacc[qt][sb] = bias[sb];          // masked keys start (and stay) at -inf
 #pragma unroll
             for (int dc = 0; dc < C::NDC; ++dc) {
                 const v8 kf = *(const v8*)(Kf + rf_idx<C>(sb, dc, lane));
@@ -252,20 +350,19 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
         float linv[C::QT], lsev[C::QT];
 #pragma unroll
         for (int qt = 0; qt < C::QT; ++qt) {
-            float m = -INFINITY, l = 0.f;
+            float m, l = 0.f;
             if (any_valid) {
+                m = fmaxf(fmaxf(sacc[qt][0][0], sacc[qt][0][1]), fmaxf(sacc[qt][0][2], sacc[qt][0][3]));
 #pragma unroll
-                for (int sb = 0; sb < C::NSB; ++sb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (bit64(vlo, vhi, sb * 4 + r)) m = fmaxf(m, sacc[qt][sb][r]);
-                m = fmaxf(m, __shfl_xor(m, 16));
-                m = fmaxf(m, __shfl_xor(m, 32));
+                for (int sb = 1; sb < C::NSB; ++sb)
+                    m = fmaxf(m, fmaxf(fmaxf(sacc[qt][sb][0], sacc[qt][sb][1]), fmaxf(sacc[qt][sb][2], sacc[qt][sb][3])));
+                m = xg_max(m);
+                const float m2 = m * LOG2E;
 #pragma unroll
                 for (int sb = 0; sb < C::NSB; ++sb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float p = bit64(vlo, vhi, sb * 4 + r) ? __expf(sacc[qt][sb][r] - m) : 0.f;
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qt][sb][r], LOG2E, -m2));
                         sacc[qt][sb][r] = p;
                         l += p;
                     }
@@ -280,9 +377,8 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
                         l += p;
                     }
             }
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
-            linv[qt] = 1.f / l;
+            l = xg_sum(l);
+            linv[qt] = __builtin_amdgcn_rcpf(l);
             lsev[qt] = m + __logf(l);
 #pragma unroll
             for (int ks = 0; ks < C::NKS; ++ks) pf[qt][ks] = pack8<T>(sacc[qt][2 * ks], sacc[qt][2 * ks + 1]);
@@ -305,13 +401,18 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
 
 #pragma unroll
         for (int qt = 0; qt < C::QT; ++qt) {
-            const int t = t0 + qt * 16 + x;
-            if (t < T_) {
+            lst[qt] = lsev[qt];
 #pragma unroll
-                for (int db = 0; db < C::NDB; ++db) store4<T>(ob + (size_t)t * HD + db * 16 + g * 4, oacc[qt][db] * linv[qt]);
-                if (g == 0) lb[t] = lsev[qt];
-            }
+            for (int db = 0; db < C::NDB; ++db) ost[qt][db] = cvt4<T>(oacc[qt][db] * linv[qt]);
         }
+    }
+    // drain: the last tile's outputs
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        const int t = tprev + qt * 16 + x;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) buf_store_v4<T>(ro, row_off<T, C>(t, row_bytes, db * 16 + g * 4), ost[qt][db]);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, lst[qt]), rl, (g == 0) ? (uint32_t)t * 4u : OOB, 0, 0);
     }
 }
 
