@@ -24,6 +24,9 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef MMGL_XATTN_ABLATE
+#define MMGL_XATTN_ABLATE 0      // timing experiments only (tools/bench_xattn.py); never set in a shipped build
+#endif
 #ifndef MMGL_XATTN_HOIST_MAX
 #define MMGL_XATTN_HOIST_MAX 16
 #endif
@@ -222,17 +225,36 @@ template <typename T, typename C> __device__ __forceinline__ uint32_t row_off(in
 
 // reductions across the four 16-lane groups that share a query row: v_permlane16_swap / v_permlane32_swap are plain
 // VALU ops (no LDS round trip like ds_bpermute): swap(v, v) leaves {lower, upper} halves side by side in the two results.
+// NB the two operands must live in DIFFERENT registers (the instruction swaps in place): the empty asm makes the copy
+// opaque so the compiler cannot fold it back into one register (same-register swap returns the lower rows twice).
+__device__ __forceinline__ void swap16(float v, float& lo, float& hi) {
+    unsigned u = __builtin_bit_cast(unsigned, v), w = u;
+    // inline asm, not __builtin_amdgcn_permlane16_swap: this clang maps BOTH result elements of the builtin to
+    // extractvalue 0 (tools/probes/permlane_probe.hip), silently returning the lower rows twice.  s_nop 1 = the two wait
+    // states a VALU write needs before a v_permlane read.  After the swap: u = {r0, r0', r2, r2'}, w = {r1, r1', r3, r3'}.
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(u), "+v"(w));
+    lo = __builtin_bit_cast(float, u);
+    hi = __builtin_bit_cast(float, w);
+}
+__device__ __forceinline__ void swap32(float v, float& lo, float& hi) {
+    unsigned u = __builtin_bit_cast(unsigned, v), w = u;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(u), "+v"(w));
+    lo = __builtin_bit_cast(float, u);
+    hi = __builtin_bit_cast(float, w);
+}
 __device__ __forceinline__ float xg_max(float v) {
-    auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    v = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
-    auto b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
+    float a, b;
+    swap16(v, a, b);
+    v = fmaxf(a, b);
+    swap32(v, a, b);
+    return fmaxf(a, b);
 }
 __device__ __forceinline__ float xg_sum(float v) {
-    auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    v = __builtin_bit_cast(float, a[0]) + __builtin_bit_cast(float, a[1]);
-    auto b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, b[0]) + __builtin_bit_cast(float, b[1]);
+    float a, b;
+    swap16(v, a, b);
+    v = a + b;
+    swap32(v, a, b);
+    return a + b;
 }
 // additive key mask in accumulator layout: 0 for a valid key, -inf otherwise.  Used as the MFMA C-input, so masked
 // scores cost no instruction in the loop (exp2(-inf) = 0 drops them from the softmax sum as well).
@@ -285,11 +307,13 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
         for (int dc = 0; dc < C::NDC; ++dc)
             qn[qt][dc] = buf_load8<T>(rq, row_off<T, C>((t0 < wg_end) ? t0 + qt * 16 + x : T_, row_bytes, dc * 32 + g * 8));
 
+#if !(MMGL_XATTN_ABLATE & 2)
     stage_row_image<T, C>(Kf, k + (size_t)b * S * HD + h * D, HD, S);
     if constexpr (C::TIMG) stage_rowmajor_image<T, C>(Vi, v + (size_t)b * S * HD + h * D, HD, S);
     else stage_row_image<T, C>(Vi, v + (size_t)b * S * HD + h * D, HD, S);
     for (int i = threadIdx.x; i < C::SPAD; i += blockDim.x) vld[i] = (i < S) ? valid[(size_t)b * S + i] : 0;
     __syncthreads();
+#endif
 
     uint32_t vlo, vhi, elo, ehi;
     lane_key_bits<C>(vld, g, S, vlo, vhi, elo, ehi);
@@ -333,6 +357,19 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q,
             for (int dc = 0; dc < C::NDC; ++dc)
                 qn[qt][dc] = buf_load8<T>(rq, row_off<T, C>((tn < wg_end) ? tn + qt * 16 + x : T_, row_bytes, dc * 32 + g * 8));
 
+#if (MMGL_XATTN_ABLATE & 1)
+        // timing ablation only: no MFMA / softmax, O := first channels of Q (streaming ceiling of this access pattern)
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            lst[qt] = 0.f;
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db) {
+                f32x4 t4 = {(float)qf[qt][db % C::NDC][0], (float)qf[qt][db % C::NDC][1], (float)qf[qt][db % C::NDC][2], (float)qf[qt][db % C::NDC][3 + db / C::NDC]};
+                ost[qt][db] = cvt4<T>(t4);
+            }
+        }
+        continue;
+#endif
         f32x4 sacc[C::QT][C::NSB];
 #pragma unroll
         for (int sb = 0; sb < C::NSB; ++sb) {
