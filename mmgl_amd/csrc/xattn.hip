@@ -780,7 +780,7 @@ int tune_env(const char* name, int dflt) {
 // rows_per_wg / nchunk: about `target` workgroups in flight (all resident in one round: 2-5 per CU), each workgroup a
 // whole number of 4-wave tile rounds where possible.
 void fwd_geometry(int B, int H, int T, int tile_rows, int& rows_per_wg, int& nchunk) {
-    static const int target = tune_env("MMGL_XATTN_TARGET_WGS", 768);
+    static const int target = tune_env("MMGL_XATTN_TARGET_WGS", 512);
     const int bh = B * H;
     int nc = (target + bh / 2) / bh;
     const int maxc = (T + tile_rows - 1) / tile_rows;
