@@ -239,9 +239,247 @@ int launch_transpose(const T* in, const T* yact, T* out, T* colsum, int R, int C
     return MMGL_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward GEMMs without transposes (bf16).   out[RB][RA] = scale * sum_k  B(k, rb) * A(k, ra)   (+= if accumulate)
+//   dgrad: out = dx[M][K_in],  A = W[N][K_in] stored k-major (TA), B = dy[M][N] stored row-major, contraction over N
+//   wgrad: out = dW[N][K_in],  A = x[M][K_in] k-major (TA), B = dy[M][N] k-major (TB), contraction over M
+// A k-major operand tile sits in LDS exactly as it is in memory ([64 k][128 cols], coalesced 256-B rows, row stride
+// 288 B) and its MFMA fragments come out of ds_read_b64_tr_b16: per 16-lane group, lane i points at 4 consecutive
+// columns of k-row 4g + (i>>2) and receives the 4 k-values of column i&15.  Two reads (k +0, +16) give the k order
+// {4g..4g+3, 16+4g..}; a row-major partner operand is read in the same order with two ds_read_b64 (any k permutation
+// is legal when both operands share it).  The ReLU mask of fc1 (dy * (y > 0)) is applied while staging.
+constexpr int KROW = 288;                            // bytes per k-row of a k-major tile (256 + 32 pad: conflict-free tr reads)
+constexpr int TX_TILE_BYTES = 64 * KROW;             // 18 KiB >= the 16 KiB of a row-major tile
+
+__device__ __forceinline__ bf16x8 tfrag_kmajor(const char* tile, int blk, int ks, int lane) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int i = lane & 15, g = lane >> 4;
+    const char* p = tile + (ks * 32 + 4 * g + (i >> 2)) * KROW + (blk * 16 + (i & 3) * 4) * 2;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * KROW));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+// row-major (swizzled) tile, same k order as tfrag_kmajor: k = 32 ks + {4g..4g+3, 16+4g..16+4g+3}
+__device__ __forceinline__ bf16x8 rfrag_perm(const char* tile, int row, int ks, int g) {
+    const bf16x4 lo = *(const bf16x4*)(tile + swz(row, ks * 4 + (g >> 1)) + (g & 1) * 8);
+    const bf16x4 hi = *(const bf16x4*)(tile + swz(row, ks * 4 + 2 + (g >> 1)) + (g & 1) * 8);
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+
+template <bool TB, bool MASK>
+__global__ __launch_bounds__(256) void gemm_tx_kernel(const bf16* __restrict__ Aop, int lda, const bf16* __restrict__ Bop,
+                                                      int ldb, const bf16* __restrict__ Ymask, bf16* __restrict__ Out,
+                                                      int RA, int RB, int K, float scale, int accumulate, int tiles_a,
+                                                      int tiles_b) {
+    typedef bf16x8 chunk_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                          // [2][TX_TILE_BYTES]  k-major
+    char* sB = smem + 2 * TX_TILE_BYTES;      // [2][TX_TILE_BYTES]  k-major (TB) or row-major swizzled
+    const int vid = xcd_remap(blockIdx.x, tiles_a * tiles_b);
+    const int ta = vid / tiles_b, tb = vid % tiles_b;          // consecutive ids share the A panel
+    const int a0 = ta * 128, b0 = tb * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 15, g = lane >> 4;
+    const int wa = wave >> 1, wb = wave & 1;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = vzero<f32x4>();
+
+    const int nk = (K + 63) / 64;
+    chunk_t ra[4], rb[4];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256;
+            {   // A: k-major [64][128]
+                const int row = id >> 4, c = id & 15;
+                const int kk = k0 + row, col = a0 + c * 8;
+                ra[i] = (kk < K && col < RA) ? *(const chunk_t*)(Aop + (size_t)kk * lda + col) : vzero<chunk_t>();
+            }
+            if constexpr (TB) {
+                const int row = id >> 4, c = id & 15;
+                const int kk = k0 + row, col = b0 + c * 8;
+                const bool ok = kk < K && col < RB;
+                chunk_t v = ok ? *(const chunk_t*)(Bop + (size_t)kk * ldb + col) : vzero<chunk_t>();
+                if constexpr (MASK) {
+                    if (ok) {
+                        const chunk_t y = *(const chunk_t*)(Ymask + (size_t)kk * ldb + col);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = ((float)y[e] > 0.f) ? v[e] : (bf16)0.f;
+                    }
+                }
+                rb[i] = v;
+            } else {
+                const int row = id >> 3, c = id & 7;
+                const int kc = k0 + c * 8;
+                const bool ok = b0 + row < RB && kc < K;
+                chunk_t v = ok ? *(const chunk_t*)(Bop + (size_t)(b0 + row) * ldb + kc) : vzero<chunk_t>();
+                if constexpr (MASK) {
+                    if (ok) {
+                        const chunk_t y = *(const chunk_t*)(Ymask + (size_t)(b0 + row) * ldb + kc);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = ((float)y[e] > 0.f) ? v[e] : (bf16)0.f;
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256;
+            *(chunk_t*)(sA + buf * TX_TILE_BYTES + (id >> 4) * KROW + (id & 15) * 16) = ra[i];
+            if constexpr (TB) *(chunk_t*)(sB + buf * TX_TILE_BYTES + (id >> 4) * KROW + (id & 15) * 16) = rb[i];
+            else *(chunk_t*)(sB + buf * TX_TILE_BYTES + swz(id >> 3, id & 7)) = rb[i];
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char* tA = sA + buf * TX_TILE_BYTES;
+        const char* tB = sB + buf * TX_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = tfrag_kmajor(tA, wa * 4 + i, ks, lane);
+                if constexpr (TB) fb[i] = tfrag_kmajor(tB, wb * 4 + i, ks, lane);
+                else fb[i] = rfrag_perm(tB, wb * 64 + i * 16 + x, ks, g);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(acc[i][j], fa[i], fb[j]);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rbi = b0 + wb * 64 + j * 16 + x;
+        if (rbi >= RB) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rai = a0 + wa * 64 + i * 16 + g * 4;
+            if (rai >= RA) continue;
+            f32x4 v = acc[i][j] * scale;
+            bf16* op = Out + (size_t)rbi * RA + rai;
+            if (accumulate) {
+                const bf16x4 ov = *(const bf16x4*)op;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
+            }
+            *(bf16x4*)op = __builtin_convertvector(v, bf16x4);
+        }
+    }
+}
+
+// column sums of dy (optionally ReLU-masked by y > 0): part[split][N] fp32, then colsum_finish folds the splits.
+template <typename T, bool MASK>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, const T* __restrict__ y, float* __restrict__ part,
+                                                     int M, int N) {
+    typedef typename GT<T>::chunk_t V;
+    constexpr int VN = GT<T>::VN;
+    __shared__ float red[16][16 * 8 + 1];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int col = (blockIdx.x * 16 + cx) * VN;
+    float a[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) a[e] = 0.f;
+    if (col < N) {
+        const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+        const int r0 = blockIdx.y * rows_per, r1 = min(r0 + rows_per, M);
+        for (int r = r0 + ry; r < r1; r += 16) {
+            const V d = *(const V*)(dy + (size_t)r * N + col);
+            if constexpr (MASK) {
+                const V yy = *(const V*)(y + (size_t)r * N + col);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) a[e] += ((float)yy[e] > 0.f) ? (float)d[e] : 0.f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < VN; ++e) a[e] += (float)d[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VN; ++e) red[ry][cx * VN + e] = a[e];
+    __syncthreads();
+    if (ry == 0 && col < N) {
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][cx * VN + e];
+            part[(size_t)blockIdx.y * N + col + e] = t;
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, T* __restrict__ out, int N, int splits,
+                                                            float scale, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float t = 0.f;
+    for (int s = 0; s < splits; ++s) t += part[(size_t)s * N + c];
+    t *= scale;
+    if (accumulate) t += (float)out[c];
+    out[c] = (T)t;
+}
+constexpr int COLSUM_SPLITS = 16;
+
+template <typename T>
+int launch_colsum(const T* dy, const T* y, T* out, float* part, int M, int N, float scale, int accumulate, hipStream_t st) {
+    constexpr int VN = GT<T>::VN;
+    if (N % VN) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "bias gradient: out_features %d must be a multiple of %d", N, VN);
+    dim3 grid(cdiv(N, 16 * VN), COLSUM_SPLITS);
+    if (y) hipLaunchKernelGGL((colsum_kernel<T, true>), grid, dim3(256), 0, st, dy, y, part, M, N);
+    else hipLaunchKernelGGL((colsum_kernel<T, false>), grid, dim3(256), 0, st, dy, y, part, M, N);
+    hipLaunchKernelGGL(colsum_finish_kernel<T>, dim3(cdiv(N, 256)), dim3(256), 0, st, part, out, N, COLSUM_SPLITS, scale, accumulate);
+    MMGL_CHECK_LAUNCH("colsum");
+    return MMGL_OK;
+}
+
+int launch_gemm_tx(bool tb, const bf16* Aop, int lda, const bf16* Bop, int ldb, const bf16* ymask, bf16* Out, int RA, int RB,
+                   int K, float scale, int accumulate, hipStream_t st) {
+    MMGL_CHECK_ARG(RA > 0 && RB > 0 && K > 0, "gemm_tx: bad sizes");
+    if (RA % 8 || (tb ? RB % 8 : K % 8)) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm_tx: feature dims must be multiples of 8");
+    const int tiles_a = cdiv(RA, 128), tiles_b = cdiv(RB, 128);
+    const size_t lds = 4 * TX_TILE_BYTES;
+    const void* kern;
+    if (tb) kern = ymask ? (const void*)gemm_tx_kernel<true, true> : (const void*)gemm_tx_kernel<true, false>;
+    else kern = ymask ? (const void*)gemm_tx_kernel<false, true> : (const void*)gemm_tx_kernel<false, false>;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    dim3 grid(tiles_a * tiles_b), block(256);
+#define TX_LAUNCH(TBV, MK) hipLaunchKernelGGL((gemm_tx_kernel<TBV, MK>), grid, block, lds, st, Aop, lda, Bop, ldb, ymask, Out, RA, RB, K, scale, accumulate, tiles_a, tiles_b)
+    if (tb) { if (ymask) TX_LAUNCH(true, true); else TX_LAUNCH(true, false); }
+    else { if (ymask) TX_LAUNCH(false, true); else TX_LAUNCH(false, false); }
+#undef TX_LAUNCH
+    MMGL_CHECK_LAUNCH("gemm_tx");
+    return MMGL_OK;
+}
+
 template <typename T>
 int linear_dgrad(const T* dy, const T* y, const T* W, T* dx, char* ws, int M, int N, int K, int act, float scale, hipStream_t st) {
-    // ws: W^T [K,N] | dyp [M,N] (only with an activation)
+    if constexpr (sizeof(T) == 2) {     // bf16: no transposes, no dyp materialisation
+        (void)ws;
+        return launch_gemm_tx(false, (const bf16*)W, K, (const bf16*)dy, N, act == MMGL_ACT_RELU ? (const bf16*)y : nullptr, (bf16*)dx,
+                              K, M, N, scale, 0, st);
+    }
+    // fp32 (parity path): W^T [K,N] | dyp [M,N] (only with an activation) in ws
     if (N % GT<T>::VN) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "linear_dgrad: out_features %d must be a multiple of %d", N, GT<T>::VN);
     T* Wt = (T*)ws;
     T* dyp = (T*)(ws + align_up((size_t)K * ((size_t)(N + 7) / 8 * 8) * sizeof(T), 256));
@@ -264,7 +502,13 @@ int linear_dgrad(const T* dy, const T* y, const T* W, T* dx, char* ws, int M, in
 template <typename T>
 int linear_wgrad(const T* dy, const T* y, const T* x, T* dW, T* dbias, char* ws, int M, int N, int K, int act, float scale,
                  int accumulate, hipStream_t st) {
-    // ws: dyp^T [N,M] | x^T [K,M]
+    if constexpr (sizeof(T) == 2) {     // bf16: both operands k-major straight from memory; ws = bias partials
+        const bf16* ym = act == MMGL_ACT_RELU ? (const bf16*)y : nullptr;
+        int rc = launch_gemm_tx(true, (const bf16*)x, K, (const bf16*)dy, N, ym, (bf16*)dW, K, N, M, scale, accumulate, st);
+        if (rc || !dbias) return rc;
+        return launch_colsum<T>(dy, act == MMGL_ACT_RELU ? y : nullptr, dbias, (float*)ws, M, N, scale, accumulate, st);
+    }
+    // fp32 (parity path): dyp^T [N,M] | x^T [K,M] in ws
     T* dyT = (T*)ws;
     T* xT = (T*)(ws + align_up((size_t)N * ((size_t)(M + 7) / 8 * 8) * sizeof(T), 256));
     int rc = launch_transpose<T>(dy, act == MMGL_ACT_RELU ? y : nullptr, dyT, dbias, M, N, scale, accumulate, st);
@@ -280,6 +524,7 @@ size_t dgrad_ws(int M, int N, int K, int act, size_t esz) {
 }
 size_t wgrad_ws(int M, int N, int K, size_t esz) {
     const size_t Mp = (size_t)(M + 7) / 8 * 8;
+    if (esz == 2) return align_up((size_t)COLSUM_SPLITS * N * sizeof(float), 256);
     return align_up((size_t)N * Mp * esz, 256) + align_up((size_t)K * Mp * esz, 256);
 }
 
