@@ -123,6 +123,11 @@ size_t mmgl_linear_wgrad_workspace(int M, int N, int K, int dtype);
 int mmgl_linear_wgrad(const void* dy, const void* y, const void* x, void* dW, void* dbias, void* workspace,
                       size_t workspace_bytes, int M, int N, int K, int act, float out_scale, int accumulate,
                       int dtype, void* stream);
+/* Whole backward of one linear in a single call: dyp is formed once, then dx / dW / dbias (each may be NULL). */
+size_t mmgl_linear_bwd_workspace(int M, int N, int K, int act, int dtype);
+int mmgl_linear_bwd(const void* dy, const void* y, const void* x, const void* W, void* dx, void* dW, void* dbias,
+                    void* workspace, size_t workspace_bytes, int M, int N, int K, int act, float out_scale,
+                    int accumulate, int dtype, void* stream);
 /* out[C,ld] = in[R,C]^T, ld = R rounded up to a whole 16-byte chunk (zero padded) */
 int mmgl_transpose(const void* in, void* out, int R, int C, int dtype, void* stream);
 

@@ -473,11 +473,28 @@ int launch_gemm_tx(bool tb, const bf16* Aop, int lda, const bf16* Bop, int ldb, 
 }
 
 template <typename T>
+int launch_relu_mask(const T* dy, const T* y, T* out, size_t n, float scale, hipStream_t st) {
+    int blocks = (int)((n / GT<T>::VN + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(relu_mask_kernel<T>, dim3(blocks), dim3(256), 0, st, dy, y, out, n, scale);
+    MMGL_CHECK_LAUNCH("relu_mask");
+    return MMGL_OK;
+}
+
+template <typename T>
 int linear_dgrad(const T* dy, const T* y, const T* W, T* dx, char* ws, int M, int N, int K, int act, float scale, hipStream_t st) {
-    if constexpr (sizeof(T) == 2) {     // bf16: no transposes, no dyp materialisation
-        (void)ws;
-        return launch_gemm_tx(false, (const bf16*)W, K, (const bf16*)dy, N, act == MMGL_ACT_RELU ? (const bf16*)y : nullptr, (bf16*)dx,
-                              K, M, N, scale, 0, st);
+    if constexpr (sizeof(T) == 2) {     // bf16: no transposes; dyp = dy*scale*(y>0) is materialised ONCE (masking inside the
+        // GEMM would re-read y for every output tile column: 16x the L2 traffic at fc1's shape)
+        const bf16* a = (const bf16*)dy;
+        float sc = scale;
+        if (act == MMGL_ACT_RELU) {
+            int rc = launch_relu_mask<T>(dy, y, (T*)ws, (size_t)M * N, scale, st);
+            if (rc) return rc;
+            a = (const bf16*)ws;
+            sc = 1.f;
+        }
+        return launch_gemm_tx(false, (const bf16*)W, K, a, N, nullptr, (bf16*)dx, K, M, N, sc, 0, st);
     }
     // fp32 (parity path): W^T [K,N] | dyp [M,N] (only with an activation) in ws
     if (N % GT<T>::VN) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "linear_dgrad: out_features %d must be a multiple of %d", N, GT<T>::VN);
@@ -502,11 +519,20 @@ int linear_dgrad(const T* dy, const T* y, const T* W, T* dx, char* ws, int M, in
 template <typename T>
 int linear_wgrad(const T* dy, const T* y, const T* x, T* dW, T* dbias, char* ws, int M, int N, int K, int act, float scale,
                  int accumulate, hipStream_t st) {
-    if constexpr (sizeof(T) == 2) {     // bf16: both operands k-major straight from memory; ws = bias partials
-        const bf16* ym = act == MMGL_ACT_RELU ? (const bf16*)y : nullptr;
-        int rc = launch_gemm_tx(true, (const bf16*)x, K, (const bf16*)dy, N, ym, (bf16*)dW, K, N, M, scale, accumulate, st);
+    if constexpr (sizeof(T) == 2) {     // bf16: both operands k-major straight from memory; ws = [dyp] | bias partials
+        const bf16* a = (const bf16*)dy;
+        float sc = scale;
+        char* part = ws;
+        if (act == MMGL_ACT_RELU) {
+            int rc = launch_relu_mask<T>(dy, y, (T*)ws, (size_t)M * N, scale, st);
+            if (rc) return rc;
+            a = (const bf16*)ws;
+            sc = 1.f;
+            part = ws + align_up((size_t)M * N * sizeof(T), 256);
+        }
+        int rc = launch_gemm_tx(true, (const bf16*)x, K, a, N, nullptr, (bf16*)dW, K, N, M, sc, accumulate, st);
         if (rc || !dbias) return rc;
-        return launch_colsum<T>(dy, act == MMGL_ACT_RELU ? y : nullptr, dbias, (float*)ws, M, N, scale, accumulate, st);
+        return launch_colsum<T>((const T*)a, nullptr, dbias, (float*)part, M, N, sc, accumulate, st);
     }
     // fp32 (parity path): dyp^T [N,M] | x^T [K,M] in ws
     T* dyT = (T*)ws;
@@ -520,11 +546,12 @@ int linear_wgrad(const T* dy, const T* y, const T* x, T* dW, T* dbias, char* ws,
 
 size_t dgrad_ws(int M, int N, int K, int act, size_t esz) {
     const size_t Np = (size_t)(N + 7) / 8 * 8;
+    if (esz == 2) return act ? align_up((size_t)M * N * esz, 256) : 256;
     return align_up((size_t)K * Np * esz, 256) + (act ? align_up((size_t)M * N * esz, 256) : 0);
 }
 size_t wgrad_ws(int M, int N, int K, size_t esz) {
     const size_t Mp = (size_t)(M + 7) / 8 * 8;
-    if (esz == 2) return align_up((size_t)COLSUM_SPLITS * N * sizeof(float), 256);
+    if (esz == 2) return align_up((size_t)M * N * esz, 256) + align_up((size_t)COLSUM_SPLITS * N * sizeof(float), 256);
     return align_up((size_t)N * Mp * esz, 256) + align_up((size_t)K * Mp * esz, 256);
 }
 
@@ -617,6 +644,55 @@ extern "C" int mmgl_linear_wgrad(const void* dy, const void* y, const void* x, v
     DT_SWITCH("mmgl_linear_wgrad",
               linear_wgrad<bf16>((const bf16*)dy, (const bf16*)y, (const bf16*)x, (bf16*)dW, (bf16*)dbias, ws, M, N, K, act, out_scale, accumulate, st),
               linear_wgrad<float>((const float*)dy, (const float*)y, (const float*)x, (float*)dW, (float*)dbias, ws, M, N, K, act, out_scale, accumulate, st));
+}
+
+// One call for the whole backward of a linear: dyp once, then dx / dW / dbias as requested (any of them may be NULL).
+template <typename T>
+int linear_bwd(const T* dy, const T* y, const T* x, const T* W, T* dx, T* dW, T* dbias, char* ws, int M, int N, int K, int act,
+               float scale, int accumulate, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        const bf16* a = (const bf16*)dy;
+        float sc = scale;
+        char* part = ws;
+        if (act == MMGL_ACT_RELU) {
+            int rc = launch_relu_mask<T>(dy, y, (T*)ws, (size_t)M * N, scale, st);
+            if (rc) return rc;
+            a = (const bf16*)ws;
+            sc = 1.f;
+            part = ws + align_up((size_t)M * N * sizeof(T), 256);
+        }
+        int rc = MMGL_OK;
+        if (dx) rc = launch_gemm_tx(false, (const bf16*)W, K, a, N, nullptr, (bf16*)dx, K, M, N, sc, 0, st);
+        if (!rc && dW) rc = launch_gemm_tx(true, (const bf16*)x, K, a, N, nullptr, (bf16*)dW, K, N, M, sc, accumulate, st);
+        if (!rc && dbias) rc = launch_colsum<T>((const T*)a, nullptr, dbias, (float*)part, M, N, sc, accumulate, st);
+        return rc;
+    } else {
+        int rc = MMGL_OK;
+        if (dx) rc = linear_dgrad<T>(dy, y, W, dx, ws, M, N, K, act, scale, st);
+        if (!rc && (dW || dbias)) {
+            MMGL_CHECK_ARG(dW, "mmgl_linear_bwd: fp32 path needs dW when dbias is requested");
+            rc = linear_wgrad<T>(dy, y, x, dW, dbias, ws, M, N, K, act, scale, accumulate, st);
+        }
+        return rc;
+    }
+}
+
+extern "C" size_t mmgl_linear_bwd_workspace(int M, int N, int K, int act, int dtype) {
+    const size_t esz = dtype == MMGL_BF16 ? 2 : 4;
+    const size_t a = dgrad_ws(M, N, K, act, esz), b = wgrad_ws(M, N, K, esz);
+    return a > b ? a : b;
+}
+
+extern "C" int mmgl_linear_bwd(const void* dy, const void* y, const void* x, const void* W, void* dx, void* dW, void* dbias,
+                               void* workspace, size_t workspace_bytes, int M, int N, int K, int act, float out_scale,
+                               int accumulate, int dtype, void* stream) {
+    MMGL_CHECK_ARG(dy && x && W && workspace && (act == MMGL_ACT_NONE || y), "mmgl_linear_bwd: null pointer");
+    MMGL_CHECK_ARG(workspace_bytes >= mmgl_linear_bwd_workspace(M, N, K, act, dtype), "mmgl_linear_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    DT_SWITCH("mmgl_linear_bwd",
+              linear_bwd<bf16>((const bf16*)dy, (const bf16*)y, (const bf16*)x, (const bf16*)W, (bf16*)dx, (bf16*)dW, (bf16*)dbias, ws, M, N, K, act, out_scale, accumulate, st),
+              linear_bwd<float>((const float*)dy, (const float*)y, (const float*)x, (const float*)W, (float*)dx, (float*)dW, (float*)dbias, ws, M, N, K, act, out_scale, accumulate, st));
 }
 
 extern "C" int mmgl_lora_linear_fwd(const void* x, const void* W, const void* bias, const void* A, const void* Bm, void* y,

@@ -210,21 +210,19 @@ class _Linear(torch.autograd.Function):
         N = w.shape[0]
         dy2 = dy.contiguous().view(M, N)
         code = dtype_code(x2)
-        dx = dw = db = None
-        if ctx.need[0]:
-            dx = torch.empty_like(x2)
-            ws = _ws(lib().mmgl_linear_dgrad_workspace(M, N, K, act, code), x2.device)
-            _lib.call("mmgl_linear_dgrad", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x2.element_size()), ptr(dy2), ptr(y), ptr(w), ptr(dx), ptr(ws), ws.numel(), M, N, K, act, out_scale, code,
-                                          stream_ptr())
+        dx = torch.empty_like(x2) if ctx.need[0] else None
+        want_w = ctx.need[1] or ctx.need[2]
+        dw = torch.empty_like(w) if want_w else None
+        db = torch.empty(N, dtype=x2.dtype, device=x2.device) if ctx.need[2] else None
+        ws = _ws(lib().mmgl_linear_bwd_workspace(M, N, K, act, code), x2.device)
+        _lib.call("mmgl_linear_bwd", dict(flops=2.0 * M * N * K * (int(dx is not None) + int(dw is not None)),
+                                         bytes=float(M * K + N * K + M * N) * x2.element_size()),
+                  ptr(dy2), ptr(y), ptr(x2), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), ws.numel(), M, N, K, act, out_scale, 0, code,
+                  stream_ptr())
+        if dx is not None:
             dx = dx.view(shape)
-        if ctx.need[1] or ctx.need[2]:
-            dw = torch.empty_like(w)
-            db = torch.empty(N, dtype=x2.dtype, device=x2.device) if ctx.need[2] else None
-            ws = _ws(lib().mmgl_linear_wgrad_workspace(M, N, K, code), x2.device)
-            _lib.call("mmgl_linear_wgrad", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x2.element_size()), ptr(dy2), ptr(y), ptr(x2), ptr(dw), ptr(db), ptr(ws), ws.numel(), M, N, K, act,
-                                          out_scale, 0, code, stream_ptr())
-            dw = dw.to(wdt) if ctx.need[1] else None
-            db = db.to(bdt) if db is not None else None
+        dw = dw.to(wdt) if (dw is not None and ctx.need[1]) else None
+        db = db.to(bdt) if db is not None else None
         return dx, dw, db, None, None
 
 
