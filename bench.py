@@ -150,6 +150,23 @@ def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1):
                        f"fp32 torch oracle (oracle/), {cores} threads", loss=float(loss))
 
 
+def pmc_traffic(B, lm_cfg, cfg, dtype):
+    """HBM bytes per launch of xattn_fwd_kernel from the committed PMC collection (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes, gfx950 x2 fetch correction applied: profiles/r1_pmc_xattn_*.json) when it was taken at this exact
+    shape; None otherwise -- PMC counters cannot be read from inside this process."""
+    path = os.path.join(ROOT, "profiles", f"r1_pmc_xattn_B{B}_{dtype}.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        c = d["config"]
+        if (c["B"], c["H"], c["S"], c["D"]) == (B, lm_cfg.num_attention_heads, (cfg["nt"] + cfg["ni"]) * 4,
+                                               lm_cfg.hidden_size // lm_cfg.num_attention_heads) and c["T"] == 640:
+            return d["kernels"]["xattn_fwd_kernel"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,7 +270,8 @@ def main():
                 sec = x["ms_avg"] * 1e-3
                 gbs = alg / sec / 1e9
                 line["roofline"] = {"kernel": "xattn_fwd_kernel (mmgl_xattn_fwd)", "bound": "hbm", "achieved": round(gbs, 1),
-                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                    "traffic": pmc_traffic(args.batch, lm_cfg, cfg, args.dtype),
                                     "us_per_launch": round(x["ms_avg"] * 1e3, 2), "launches": x["calls"],
                                     "algorithmic_bytes_per_launch": alg, "tflops": round(flops / sec / 1e12, 2),
                                     "frac_of_bf16_mfma_peak": round(flops / sec / 1e12 / MFMA_BF16_PEAK_TF, 4)}
