@@ -503,6 +503,36 @@ class MPTForCausalLM(MPTPreTrainedModel):
                                       attentions=outputs.attentions)
 
 
+class _PatchEmbedLinear(nn.Conv2d):
+    """CLIP's patch embedding is a stride == kernel Conv2d, i.e. a GEMM over flattened patches.  MIOpen has no tuned bf16
+    kernel for it here and falls back to `naive_conv_*` (8 ms / step at B=8, profiles/r1_b); the GEMM form is the same
+    arithmetic.  Parameters and state-dict keys are untouched (the instance's class is swapped in place)."""
+
+    def forward(self, x):
+        p = self.kernel_size[0]
+        if self.kernel_size != self.stride or self.kernel_size[0] != self.kernel_size[1] or self.padding != (0, 0) or x.shape[-1] % p or x.shape[-2] % p:
+            return super().forward(x)
+        n, c, hh, ww = x.shape
+        cols = x.view(n, c, hh // p, p, ww // p, p).permute(0, 2, 4, 1, 3, 5).reshape(n * (hh // p) * (ww // p), c * p * p)
+        y = F.linear(cols, self.weight.view(self.out_channels, -1), self.bias)
+        return y.view(n, hh // p, ww // p, self.out_channels).permute(0, 3, 1, 2)
+
+
+def _conv_patch_embed_as_gemm(module: nn.Module):
+    for m in module.modules():
+        if type(m) is nn.Conv2d and m.kernel_size == m.stride and m.groups == 1:
+            m.__class__ = _PatchEmbedLinear
+
+
+def _valid_rows(pos_ids):
+    """Indices (device LongTensor) of neighbor slots with pos_id > 0, or None when every slot is valid OR some sample has
+    no valid slot at all (then padded slots DO matter: a fully-masked sample attends uniformly over all its keys)."""
+    valid = (pos_ids > 0).cpu()                       # [B, N], tiny; the one host sync of the neighbor pass
+    if bool(valid.all()) or not bool(valid.any(dim=1).all()):
+        return None
+    return valid.reshape(-1).nonzero().squeeze(1).to(pos_ids.device)
+
+
 class TextPooler(nn.Module):
     """CLS token -> Linear -> tanh (reference :879-893)."""
 
@@ -563,6 +593,10 @@ class CrossAttentionModel(nn.Module):
             self.visual_model.eval()
             for p in self.visual_model.parameters():
                 p.requires_grad = False
+            _conv_patch_embed_as_gemm(self.visual_model)
+        # Padded neighbor slots (pos_id 0) are masked keys: they can influence neither the logits nor any gradient, so
+        # the frozen encoders skip them (the reference encodes '' texts and all-zero images, data.py:444-454).
+        self.skip_padded_neighbors = getattr(args, "skip_padded_neighbors", True)
 
         if self.args.freeze_lm:
             print("Freezing the LM.")
@@ -607,20 +641,37 @@ class CrossAttentionModel(nn.Module):
     def get_text_embs(self, input_ids, attention_mask, pos_ids=None):
         """[B,N,L] ids -> [B,N,n_text_tokens,d]  (reference :978-1004)."""
         batch_size, neighbor_num, seq_len = input_ids.shape
+        ids, am = input_ids.reshape(-1, seq_len), attention_mask.reshape(-1, seq_len)
+        rows = _valid_rows(pos_ids) if (self.skip_padded_neighbors and pos_ids is not None) else None
         with torch.no_grad():
-            outputs = self.text_model(input_ids=input_ids.reshape(-1, seq_len), attention_mask=attention_mask.reshape(-1, seq_len))
+            if rows is not None:
+                ids, am = ids.index_select(0, rows), am.index_select(0, rows)
+            outputs = self.text_model(input_ids=ids, attention_mask=am)
+            enc = outputs.pooler_output if "clip" in self.args.text_model else outputs.last_hidden_state[:, 0]
+            if rows is not None:
+                full = enc.new_zeros(batch_size * neighbor_num, enc.shape[-1])
+                enc = full.index_copy_(0, rows, enc)
         if "clip" in self.args.text_model:
-            pooled = outputs.pooler_output
+            pooled = enc
         else:
-            pooled = self.text_pooler(outputs.last_hidden_state)
+            pooled = torch.tanh(ops.linear(enc.contiguous(), self.text_pooler.dense.weight, self.text_pooler.dense.bias))
         return self._project(pooled, self.text_embeddings, self.text_position_embeddings, pos_ids, batch_size, self.n_text_tokens)
 
     def get_visual_embs(self, pixel_values, pos_ids=None):
         """[B,N,3,H,W] pixels -> [B,N,n_visual_tokens,d]  (reference :1006-1027)."""
         batch_size, neighbor_num, pixel, width, height = pixel_values.shape
+        rows = _valid_rows(pos_ids) if (self.skip_padded_neighbors and pos_ids is not None) else None
         with torch.no_grad():
-            pv = pixel_values.reshape(-1, pixel, width, height).to(next(self.visual_model.parameters()).dtype)
-            pooled = self.visual_model(pv).pooler_output
+            pv = pixel_values.reshape(-1, pixel, width, height)
+            if rows is not None:
+                pv = pv.index_select(0, rows)
+            hidden = self.visual_model.config.hidden_size
+            if pv.shape[0] == 0:
+                pooled = pixel_values.new_zeros(0, hidden, dtype=next(self.visual_model.parameters()).dtype)
+            else:
+                pooled = self.visual_model(pv.to(next(self.visual_model.parameters()).dtype)).pooler_output
+            if rows is not None:
+                pooled = pooled.new_zeros(batch_size * neighbor_num, hidden).index_copy_(0, rows, pooled)
         return self._project(pooled, self.visual_embeddings, self.visual_position_embeddings, pos_ids, batch_size, self.n_visual_tokens)
 
     def train(self, mode=True):
