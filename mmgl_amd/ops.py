@@ -234,6 +234,18 @@ def linear(x, weight, bias=None, act="none", out_scale=1.0):
     code = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU}.get(act)
     if code is None:
         raise ValueError(f"linear: activation {act!r} is not fused (supported: none, relu)")
+    # The MFMA kernels move 16-byte chunks along K and 4 outputs per lane along N: odd feature counts (e.g. the
+    # Laplacian-PE input width k = N_neighbors - 4) are zero-padded here; autograd slices the gradients back.
+    K, N = weight.shape[1], weight.shape[0]
+    kq = 8 if x.dtype == torch.bfloat16 else 4
+    pk, pn = (-K) % kq, (-N) % 8
+    if pk or pn:
+        x = torch.nn.functional.pad(x, (0, pk)) if pk else x
+        weight = torch.nn.functional.pad(weight, (0, pk, 0, pn))
+        if bias is not None and pn:
+            bias = torch.nn.functional.pad(bias, (0, pn))
+        y = _Linear.apply(x, weight, bias, code, float(out_scale))
+        return y[..., :N] if pn else y
     return _Linear.apply(x, weight, bias, code, float(out_scale))
 
 
