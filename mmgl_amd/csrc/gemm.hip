@@ -14,6 +14,7 @@
 // dgrad / wgrad are the same kernel on explicitly transposed operands (tile transpose kernel below); the ReLU
 // mask, the out_scale and the bias column-sum are fused into that transpose / mask pass.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -40,7 +41,11 @@ template <> __device__ __forceinline__ f32x8 lds_frag<float>(const char* tile, i
     return r;
 }
 
-template <typename T, int ACT>
+// GLDS = operand tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB = 8 swizzled rows per wave instruction,
+// no VGPR round trip, no ds_write pass); the XOR swizzle is applied to the SOURCE chunk index because the LDS
+// destination of an LDS-DMA is lane-linear.  Needs K % BK == 0 (no zero fill possible); row tails are clamped to a valid row
+// (their outputs are never stored).  The register-staged form remains for ragged K.
+template <typename T, int ACT, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ Y,
                                                       const T* __restrict__ bias, int M, int N, int K, float scale,
                                                       int accumulate, const T* __restrict__ X2, const T* __restrict__ W2,
@@ -92,12 +97,33 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ X, c
         }
     };
 
-    load_tile(0);
-    store_tile(0);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto glds_tile = [&](int kt, int buf) {
+        const T* xs = X; const T* ws = W; int kk = K, k0 = kt * G::BK;
+        if (kt >= nk1) { xs = X2; ws = W2; kk = K2; k0 = (kt - nk1) * G::BK; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rbase = (i * 4 + wave_u) * 8;
+            const int row = rbase + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const T* gx = xs + (size_t)min(m0 + row, M - 1) * kk + k0 + c * G::VN;
+            const T* gw = ws + (size_t)min(n0 + row, N - 1) * kk + k0 + c * G::VN;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gx,
+                                             (__attribute__((address_space(3))) void*)(sX + buf * TILE_BYTES + rbase * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,
+                                             (__attribute__((address_space(3))) void*)(sW + buf * TILE_BYTES + rbase * ROWB), 16, 0, 0);
+        }
+    };
+
+    if constexpr (GLDS) glds_tile(0, 0);
+    else { load_tile(0); store_tile(0); }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) {
+            if constexpr (GLDS) glds_tile(kt + 1, buf ^ 1);
+            else load_tile(kt + 1);
+        }
         const char* tX = sX + buf * TILE_BYTES;
         const char* tW = sW + buf * TILE_BYTES;
 #pragma unroll
@@ -113,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ X, c
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mma16(acc[i][j], fw[i], fx[j]);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+        if constexpr (!GLDS) { if (kt + 1 < nk) store_tile(buf ^ 1); }
         __syncthreads();
     }
 
@@ -207,6 +233,11 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const T* __restrict__ dy
     }
 }
 
+inline bool tune_gemm_glds() {
+    static const bool on = [] { const char* e = getenv("MMGL_GEMM_GLDS"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 template <typename T> inline int pad_k(int k) { return (k + GT<T>::VN - 1) / GT<T>::VN * GT<T>::VN; }
 
 template <typename T>
@@ -218,13 +249,17 @@ int launch_gemm(const T* X, const T* W, T* Y, const T* bias, int M, int N, int K
         MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm: K (%d) must be a multiple of %d and N (%d) of 4", K, VN, N);
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
     const size_t lds = 4 * TILE_BYTES;
-    auto k0 = gemm_nt_kernel<T, MMGL_ACT_NONE>;
-    auto k1 = gemm_nt_kernel<T, MMGL_ACT_RELU>;
-    auto kern = act == MMGL_ACT_RELU ? k1 : k0;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool glds = (K % GT<T>::BK == 0) && (!X2 || K2 % GT<T>::BK == 0) && tune_gemm_glds();
+    const void* kern;
+    if (glds) kern = act == MMGL_ACT_RELU ? (const void*)gemm_nt_kernel<T, MMGL_ACT_RELU, true> : (const void*)gemm_nt_kernel<T, MMGL_ACT_NONE, true>;
+    else kern = act == MMGL_ACT_RELU ? (const void*)gemm_nt_kernel<T, MMGL_ACT_RELU, false> : (const void*)gemm_nt_kernel<T, MMGL_ACT_NONE, false>;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, st, X, W, Y, bias, M, N, K, scale, accumulate, X2, W2, K2,
-                       tiles_m, tiles_n);
+    dim3 grid(tiles_m * tiles_n), block(256);
+#define NT_LAUNCH(A, G) hipLaunchKernelGGL((gemm_nt_kernel<T, A, G>), grid, block, lds, st, X, W, Y, bias, M, N, K, scale, accumulate, X2, W2, K2, tiles_m, tiles_n)
+    if (glds) { if (act == MMGL_ACT_RELU) NT_LAUNCH(MMGL_ACT_RELU, true); else NT_LAUNCH(MMGL_ACT_NONE, true); }
+    else { if (act == MMGL_ACT_RELU) NT_LAUNCH(MMGL_ACT_RELU, false); else NT_LAUNCH(MMGL_ACT_NONE, false); }
+#undef NT_LAUNCH
     MMGL_CHECK_LAUNCH("gemm_nt");
     return MMGL_OK;
 }
@@ -269,7 +304,20 @@ __device__ __forceinline__ bf16x8 rfrag_perm(const char* tile, int row, int ks, 
     return r;
 }
 
-template <bool TB, bool MASK>
+// k-major tile for the LDS-DMA path: 256-B rows, no padding (the DMA destination is lane-linear), 32-B slot index XORed
+// with (k-row & 7) on the SOURCE side so the 8 k-rows one tr16 cycle touches hit 8 distinct bank slots.
+__device__ __forceinline__ bf16x8 tfrag_kmajor_swz(const char* tile, int blk, int ks, int lane) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int i = lane & 15, g = lane >> 4;
+    const int row = ks * 32 + 4 * g + (i >> 2);             // row + 16 has the same (row & 7)
+    const char* p = tile + row * 256 + ((blk ^ (row & 7)) << 5) + (i & 3) * 8;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * 256));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+
+template <bool TB, bool MASK, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_tx_kernel(const bf16* __restrict__ Aop, int lda, const bf16* __restrict__ Bop,
                                                       int ldb, const bf16* __restrict__ Ymask, bf16* __restrict__ Out,
                                                       int RA, int RB, int K, float scale, int accumulate, int tiles_a,
@@ -342,12 +390,45 @@ __global__ __launch_bounds__(256) void gemm_tx_kernel(const bf16* __restrict__ A
         }
     };
 
-    load_tile(0);
-    store_tile(0);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto glds_kmajor = [&](const bf16* op, int ld, int col0, int k0, char* dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rbase = (i * 4 + wave_u) * 4;                        // 4 k-rows (1 KiB) per wave instruction
+            const int row = rbase + (lane >> 4);
+            const int s16 = lane & 15;
+            const int c16 = ((((s16 >> 1) ^ (row & 7)) << 1) | (s16 & 1));
+            const bf16* gp = op + (size_t)(k0 + row) * ld + col0 + c16 * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(dst + rbase * 256), 16, 0, 0);
+        }
+    };
+    auto glds_tile = [&](int kt, int buf) {
+        const int k0 = kt * 64;
+        glds_kmajor(Aop, lda, a0, k0, sA + buf * TX_TILE_BYTES);
+        if constexpr (TB) glds_kmajor(Bop, ldb, b0, k0, sB + buf * TX_TILE_BYTES);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rbase = (i * 4 + wave_u) * 8;
+                const int row = rbase + (lane >> 3);
+                const int c = (lane & 7) ^ ((row >> 1) & 7);
+                const bf16* gp = Bop + (size_t)min(b0 + row, RB - 1) * ldb + k0 + c * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)(sB + buf * TX_TILE_BYTES + rbase * ROWB), 16, 0, 0);
+            }
+        }
+    };
+
+    if constexpr (GLDS) glds_tile(0, 0);
+    else { load_tile(0); store_tile(0); }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) {
+            if constexpr (GLDS) glds_tile(kt + 1, buf ^ 1);
+            else load_tile(kt + 1);
+        }
         const char* tA = sA + buf * TX_TILE_BYTES;
         const char* tB = sB + buf * TX_TILE_BYTES;
 #pragma unroll
@@ -355,16 +436,19 @@ __global__ __launch_bounds__(256) void gemm_tx_kernel(const bf16* __restrict__ A
             bf16x8 fa[4], fb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                fa[i] = tfrag_kmajor(tA, wa * 4 + i, ks, lane);
-                if constexpr (TB) fb[i] = tfrag_kmajor(tB, wb * 4 + i, ks, lane);
-                else fb[i] = rfrag_perm(tB, wb * 64 + i * 16 + x, ks, g);
+                if constexpr (GLDS) fa[i] = tfrag_kmajor_swz(tA, wa * 4 + i, ks, lane);
+                else fa[i] = tfrag_kmajor(tA, wa * 4 + i, ks, lane);
+                if constexpr (TB) {
+                    if constexpr (GLDS) fb[i] = tfrag_kmajor_swz(tB, wb * 4 + i, ks, lane);
+                    else fb[i] = tfrag_kmajor(tB, wb * 4 + i, ks, lane);
+                } else fb[i] = rfrag_perm(tB, wb * 64 + i * 16 + x, ks, g);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mma16(acc[i][j], fa[i], fb[j]);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+        if constexpr (!GLDS) { if (kt + 1 < nk) store_tile(buf ^ 1); }
         __syncthreads();
     }
 #pragma unroll
@@ -458,15 +542,19 @@ int launch_gemm_tx(bool tb, const bf16* Aop, int lda, const bf16* Bop, int ldb, 
     if (RA % 8 || (tb ? RB % 8 : K % 8)) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm_tx: feature dims must be multiples of 8");
     const int tiles_a = cdiv(RA, 128), tiles_b = cdiv(RB, 128);
     const size_t lds = 4 * TX_TILE_BYTES;
-    const void* kern;
-    if (tb) kern = ymask ? (const void*)gemm_tx_kernel<true, true> : (const void*)gemm_tx_kernel<true, false>;
-    else kern = ymask ? (const void*)gemm_tx_kernel<false, true> : (const void*)gemm_tx_kernel<false, false>;
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    // LDS-DMA staging needs whole tiles along every k-major dimension and no ReLU mask (the mask is applied once, upstream)
+    const bool glds = !ymask && K % 64 == 0 && RA % 128 == 0 && (!tb || RB % 128 == 0) && tune_gemm_glds();
     dim3 grid(tiles_a * tiles_b), block(256);
-#define TX_LAUNCH(TBV, MK) hipLaunchKernelGGL((gemm_tx_kernel<TBV, MK>), grid, block, lds, st, Aop, lda, Bop, ldb, ymask, Out, RA, RB, K, scale, accumulate, tiles_a, tiles_b)
-    if (tb) { if (ymask) TX_LAUNCH(true, true); else TX_LAUNCH(true, false); }
-    else { if (ymask) TX_LAUNCH(false, true); else TX_LAUNCH(false, false); }
+#define TX_LAUNCH(TBV, MK, GL)                                                                                              \
+    do {                                                                                                                    \
+        auto kf = gemm_tx_kernel<TBV, MK, GL>;                                                                              \
+        hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+        if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));                      \
+        hipLaunchKernelGGL(kf, grid, block, lds, st, Aop, lda, Bop, ldb, ymask, Out, RA, RB, K, scale, accumulate, tiles_a, tiles_b); \
+    } while (0)
+    if (glds) { if (tb) TX_LAUNCH(true, false, true); else TX_LAUNCH(false, false, true); }
+    else if (tb) { if (ymask) TX_LAUNCH(true, true, false); else TX_LAUNCH(true, false, false); }
+    else { if (ymask) TX_LAUNCH(false, true, false); else TX_LAUNCH(false, false, false); }
 #undef TX_LAUNCH
     MMGL_CHECK_LAUNCH("gemm_tx");
     return MMGL_OK;
