@@ -128,6 +128,7 @@ class MPTAttention(nn.Module):
         self.cross_attention = cross_attention
         self.peft_type = config.peft_type
         self.v_proj = nn.Linear(self.embed_dim, self.embed_dim, bias=bias)
+        self.fused_self_attention = True
 
     # -- fused HIP path: projections with bias/scale epilogue + single-pass masked core
     def _forward_cross(self, hidden_states, neighbor_embeds, neighbor_attention_mask, layer_head_mask, output_attentions):
@@ -159,6 +160,14 @@ class MPTAttention(nn.Module):
         q = (self.q_proj(hidden_states) * self.scaling).view(bsz, tgt_len, H, D).transpose(1, 2)
         k = self.k_proj(hidden_states).view(bsz, tgt_len, H, D).transpose(1, 2)
         v = self.v_proj(hidden_states).view(bsz, tgt_len, H, D).transpose(1, 2)
+        if (self.fused_self_attention and attention_mask is not None and attention_mask.dtype == torch.bool
+                and layer_head_mask is None and not output_attentions and not (self.training and self.dropout > 0)):
+            # interim for the frozen layers (not yet a HIP kernel of this repo): torch's fused SDPA with
+            # the boolean (causal & key-valid) mask.  Same softmax as the additive finfo.min mask + clamp whenever a query
+            # row keeps at least one key, which MPTDecoder guarantees before it builds a boolean mask.
+            o = F.scaled_dot_product_attention(q, k, v, attn_mask=attention_mask, scale=1.0)
+            o = o.transpose(1, 2).reshape(bsz, tgt_len, self.embed_dim)
+            return self.out_proj(o), None, None
         w = torch.matmul(q, k.transpose(-1, -2))
         if attention_mask is not None:
             if attention_mask.size() != (bsz, 1, tgt_len, tgt_len):
@@ -316,6 +325,7 @@ class MPTDecoder(MPTPreTrainedModel):
             if self.cross_attention and (l + 1) % self.neighbor_layer_wise == 0:
                 self.neighbor_layers.append(MPTDecoderLayer(config, cross_attention=True))
         self.gradient_checkpointing = False
+        self.fused_self_attention = True
         self.post_init()
 
     def get_input_embeddings(self):
@@ -359,6 +369,12 @@ class MPTDecoder(MPTPreTrainedModel):
             raise ValueError(f"The provided attention mask has length {attention_mask.shape[1]}, but its length should be "
                              f"{seq_length} (sum of the lengths of current and past inputs)")
         causal_attention_mask = self._prepare_decoder_attention_mask(attention_mask, input_shape, inputs_embeds, 0)
+        if (self.fused_self_attention and not output_attentions and head_mask is None and self.config.attention_dropout == 0
+                and seq_length > 1 and bool((attention_mask[:, 0] != 0).all())):
+            # every query row keeps key 0 (sequences are right-padded, data.py:321-333), so no row is fully masked and the
+            # boolean (causal & key-valid) mask is equivalent to the additive one; [B,1,T,T] bool = 1/2..1/4 the bytes
+            keep = torch.ones(seq_length, seq_length, dtype=torch.bool, device=inputs_embeds.device).tril_()
+            causal_attention_mask = keep[None, None] & (attention_mask[:, None, None, :] != 0)
         key_valid = None
         if neighbor_attention_mask is not None:
             key_valid = _key_valid_from(neighbor_attention_mask).to(torch.uint8).contiguous()
