@@ -242,19 +242,21 @@ class MPTDecoderLayer(nn.Module):
         return h, attn_w
 
     def _forward_self(self, h, attention_mask, layer_head_mask, output_attentions):
+        """Frozen OPT layer: GEMMs and the attention core are torch (hipBLASLt / SDPA) in this round; the row ops around
+        them -- LayerNorm and dropout+residual -- already run on this repo's HIP kernels (one pass each instead of 2-3)."""
         residual = h
-        x = self.self_attn_layer_norm(h) if self.do_layer_norm_before else h
+        x = self._ln(self.self_attn_layer_norm, h) if self.do_layer_norm_before else h
         a, attn_w, _ = self.self_attn(x, attention_mask=attention_mask, layer_head_mask=layer_head_mask,
                                       output_attentions=output_attentions)
-        h = residual + F.dropout(a, p=self.dropout, training=self.training)
+        h = ops.gated_residual(residual, a, None, self.dropout, self.training)
         if not self.do_layer_norm_before:
-            h = self.self_attn_layer_norm(h)
+            h = self._ln(self.self_attn_layer_norm, h)
         residual = h
-        x = self.final_layer_norm(h) if self.do_layer_norm_before else h
+        x = self._ln(self.final_layer_norm, h) if self.do_layer_norm_before else h
         x = self.fc2(self.activation_fn(self.fc1(x)))
-        h = residual + F.dropout(x, p=self.dropout, training=self.training)
+        h = ops.gated_residual(residual, x, None, self.dropout, self.training)
         if not self.do_layer_norm_before:
-            h = self.final_layer_norm(h)
+            h = self._ln(self.final_layer_norm, h)
         return h, attn_w
 
     def forward(self, hidden_states, attention_mask=None, neighbor_embeds=None, neighbor_attention_mask=None,
