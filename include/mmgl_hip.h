@@ -68,6 +68,25 @@ int mmgl_xattn_bwd(const void* dout, const void* q, const void* k, const void* v
                    int B, int H, int T, int S, int D, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Causal self-attention of the (frozen) decoder layers, flash style:  O = softmax(mask(Q K^T)) V,
+ * mask = (s <= t) AND key_valid[b,s].
+ * replaces: MPTAttention.forward self branch, model/modelling_cross_attention.py:203-271 with the additive masks of
+ *           _make_causal_mask / _expand_mask (:51-79, :455-476): neither the [B,1,T,T] mask nor the [B,H,T,T] scores exist.
+ *   q [B,T,H*D] already scaled by D^-0.5 ; k, v [B,T,H*D] ; key_valid [B,T] uint8 (the LM attention_mask)
+ *   out [B,T,H*D] ; lse [B,H,T] fp32.
+ * Precondition: key_valid[b,0] == 1 for every b (right-padded sequences, wikiweb2m/data.py:321-333), so every query row
+ * keeps at least one key and the result equals the reference's finfo.min-clamped softmax; the host wrapper checks it.
+ * SURVEY.md 8(f) row 2.  Backward returns dq, dk, dv (the layers are frozen, activations still need gradients);
+ * `out` is the forward output (delta = rowsum(dO*O)); workspace >= mmgl_selfattn_bwd_workspace bytes.
+ */
+int mmgl_selfattn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out, float* lse,
+                      int B, int H, int T, int D, int dtype, void* stream);
+size_t mmgl_selfattn_bwd_workspace(int B, int H, int T);
+int mmgl_selfattn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse,
+                      const uint8_t* key_valid, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
+                      int B, int H, int T, int D, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * LayerNorm (affine, eps inside the sqrt) over the last dim.
  * replaces: nn.LayerNorm at modelling_cross_attention.py:319-320, 340-341, 349-350, 364-365, 635-636
  *   x,y [rows,cols]; gamma,beta [cols] (same dtype as x; may be NULL = no affine); mean,rstd [rows] fp32

@@ -1,0 +1,588 @@
+// Causal self-attention of the (frozen) decoder layers for gfx950, flash style:  O = softmax(mask(Q K^T)) V  with
+// mask = causal AND key-valid, exactly the softmax the reference's additive finfo.min mask + clamp produces
+// (model/modelling_cross_attention.py:51-79, 206-235, 455-476) whenever every query row keeps at least one key
+// (the caller guarantees key 0 is valid: sequences are right-padded).  SURVEY.md 8(f) row 2.
+//
+// Same lane geometry as xattn.hip (swapped products, lane = one query row, masks as the MFMA C-input, P never moves
+// between lanes, V^T / K^T fragments via ds_read_b64_tr_b16), plus the online-softmax loop over 64-key tiles that a
+// 640..2176-key sequence needs.  Backward = flash backward: delta = rowsum(dO*O) pre-pass, a dQ kernel (loop over key
+// tiles per query tile) and a dK/dV kernel (loop over query tiles per key tile, no atomics, no global partials).
+#include "attn_common.h"
+
+namespace {
+
+constexpr int KT = 64;            // keys per tile (NSB = 4)
+
+template <typename T, int D> struct SC : XC<T, D, 4, 1> {};
+
+// per-tile additive key bias in accumulator layout from the staged valid bytes (0 valid, -inf masked/absent)
+template <typename C> __device__ __forceinline__ void tile_bias(const uint8_t* vld, int g, f32x4 (&bias)[4]) {
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+        const uint32_t w = *(const uint32_t*)(vld + sb * 16 + g * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[sb][r] = ((w >> (8 * r)) & 0xffu) ? 0.f : -INFINITY;
+    }
+}
+
+// ============================================================================================ forward
+template <typename T, int D>
+__global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                           const T* __restrict__ v, const uint8_t* __restrict__ valid,
+                                                           T* __restrict__ out, float* __restrict__ lse, int B, int H,
+                                                           int T_, int nqb) {
+    typedef SC<T, D> C;
+    typedef typename Elem<T>::v8 v8;
+    constexpr int TILE = 16 * C::QT, QB = 4 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Kf = (T*)smem;
+    T* Vi = Kf + C::ROWIMG;
+    uint8_t* vld = (uint8_t*)(Vi + (C::TIMG ? C::RMIMG : C::ROWIMG));
+
+    const int vid = xcd_remap(blockIdx.x, B * H * nqb);
+    const int bh = vid / nqb, qblk = nqb - 1 - vid % nqb;        // longest (most key tiles) first
+    const int b = bh / H, h = bh % H;
+    const size_t HD = (size_t)H * D;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = lane & 15, g = lane >> 4;
+    const int t0 = qblk * QB + wave * TILE;
+    const int nkt = (min(T_, (qblk + 1) * QB) + KT - 1) / KT;
+
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t slab = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
+    const T* kb = k + (size_t)b * T_ * HD + h * D;
+    const T* vb = v + (size_t)b * T_ * HD + h * D;
+
+    v8 qf[C::QT][C::NDC];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+        for (int dc = 0; dc < C::NDC; ++dc) qf[qt][dc] = buf_load8<T>(rq, row_off<T, C>(t0 + qt * 16 + x, row_bytes, dc * 32 + g * 8));
+
+    float m[C::QT], l[C::QT];
+    f32x4 oacc[C::QT][C::NDB];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        m[qt] = -INFINITY;
+        l[qt] = 0.f;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) oacc[qt][db] = vzero<f32x4>();
+    }
+
+    for (int j = 0; j < nkt; ++j) {
+        const int s0 = j * KT;
+        __syncthreads();
+        stage_row_image<T, C>(Kf, kb + (size_t)s0 * HD, HD, T_ - s0);
+        if constexpr (C::TIMG) stage_rowmajor_image<T, C>(Vi, vb + (size_t)s0 * HD, HD, T_ - s0);
+        else stage_row_image<T, C>(Vi, vb + (size_t)s0 * HD, HD, T_ - s0);
+        for (int i = threadIdx.x; i < KT; i += blockDim.x) vld[i] = (s0 + i < T_) ? valid[(size_t)b * T_ + s0 + i] : 0;
+        __syncthreads();
+        if (s0 > t0 + TILE - 1) continue;                     // tile entirely above this wave's diagonal (wave-uniform)
+
+        f32x4 bias[4];
+        tile_bias<C>(vld, g, bias);
+        f32x4 sacc[C::QT][4];
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+            for (int qt = 0; qt < C::QT; ++qt) sacc[qt][sb] = bias[sb];
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc) {
+                const v8 kf = *(const v8*)(Kf + rf_idx<C>(sb, dc, lane));
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt) mma16(sacc[qt][sb], kf, qf[qt][dc]);
+            }
+        }
+        const bool diag = s0 + KT - 1 > t0;                   // some (key, row) pair of this wave violates s <= t
+        v8 pf[C::QT][2];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            const int t = t0 + qt * 16 + x;
+            if (diag) {
+#pragma unroll
+                for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (s0 + sb * 16 + g * 4 + r > t) sacc[qt][sb][r] = -INFINITY;
+            }
+            float tm = fmaxf(fmaxf(sacc[qt][0][0], sacc[qt][0][1]), fmaxf(sacc[qt][0][2], sacc[qt][0][3]));
+#pragma unroll
+            for (int sb = 1; sb < 4; ++sb)
+                tm = fmaxf(tm, fmaxf(fmaxf(sacc[qt][sb][0], sacc[qt][sb][1]), fmaxf(sacc[qt][sb][2], sacc[qt][sb][3])));
+            tm = xg_max(tm);
+            const float mn = fmaxf(m[qt], tm);
+            const float mn2 = (mn == -INFINITY) ? 0.f : mn * LOG2E;      // row without any allowed key yet: keep p = 0
+            const float alpha = __builtin_amdgcn_exp2f(m[qt] * LOG2E - mn2);   // m = -inf -> 0
+            m[qt] = mn;
+            float ls = 0.f;
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qt][sb][r], LOG2E, -mn2));
+                    sacc[qt][sb][r] = p;
+                    ls += p;
+                }
+            l[qt] = l[qt] * alpha + ls;                       // per-lane partial; folded across the 4 lane groups at the end
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db) oacc[qt][db] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) pf[qt][ks] = pack8<T>(sacc[qt][2 * ks], sacc[qt][2 * ks + 1]);
+        }
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                v8 vt;
+                if constexpr (C::TIMG) vt = rm_tfrag_tr16<C>(Vi, db, ks, lane);
+                else vt = load_tfrag<T, C>(Vi, Vi, db, ks, lane);
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt) mma16(oacc[qt][db], vt, pf[qt][ks]);
+            }
+    }
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        const int t = t0 + qt * 16 + x;
+        const float lt = xg_sum(l[qt]);
+        const float inv = __builtin_amdgcn_rcpf(lt);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) buf_store4<T>(ro, row_off<T, C>(t, row_bytes, db * 16 + g * 4), oacc[qt][db] * inv);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, m[qt] + __logf(lt)), rl, (g == 0) ? (uint32_t)t * 4u : OOB, 0, 0);
+    }
+}
+
+// ============================================================================================ delta = rowsum(dO * O) per head
+template <typename T, int D>
+__global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ dout, const T* __restrict__ out, float* __restrict__ delta,
+                                                     int B, int H, int T_) {
+    typedef typename Elem<T>::v8 v8;
+    // one thread = one (b, t, h, 8-channel chunk); D/8 consecutive threads share a head -> shuffle reduce
+    constexpr int CPH = D / 8;
+    const size_t total = (size_t)B * T_ * H * CPH;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (total + 63) / 64 * 64; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        if (i < total) {
+            const v8 a = *(const v8*)(dout + i * 8), c = *(const v8*)(out + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
+        }
+#pragma unroll
+        for (int o = CPH / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (i < total && (i % CPH) == 0) {
+            const size_t bth = i / CPH;                      // (b*T + t)*H + h
+            const int h = (int)(bth % H);
+            const size_t bt = bth / H;
+            const int t = (int)(bt % T_), b = (int)(bt / T_);
+            delta[((size_t)b * H + h) * T_ + t] = s;
+        }
+    }
+}
+
+// ============================================================================================ backward: dQ
+template <typename T, int D>
+__global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restrict__ dout, const T* __restrict__ q,
+                                                              const T* __restrict__ k, const T* __restrict__ v,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              const uint8_t* __restrict__ valid, T* __restrict__ dq, int B, int H,
+                                                              int T_, int nqb) {
+    typedef XC<T, D, 4, 2> C;
+    typedef typename Elem<T>::v8 v8;
+    constexpr int TILE = 16 * C::QT, QB = 4 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ki = (T*)smem;                                          // row-major (bf16) / row image (f32)
+    T* Vf = Ki + (C::TIMG ? C::RMIMG : C::ROWIMG);
+    uint8_t* vld = (uint8_t*)(Vf + C::ROWIMG);
+
+    const int vid = xcd_remap(blockIdx.x, B * H * nqb);
+    const int bh = vid / nqb, qblk = nqb - 1 - vid % nqb;
+    const int b = bh / H, h = bh % H;
+    const size_t HD = (size_t)H * D;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = lane & 15, g = lane >> 4;
+    const int t0 = qblk * QB + wave * TILE;
+    const int nkt = (min(T_, (qblk + 1) * QB) + KT - 1) / KT;
+
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t slab = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(dout + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dq + (size_t)b * T_ * HD + h * D, slab);
+    const T* kb = k + (size_t)b * T_ * HD + h * D;
+    const T* vb = v + (size_t)b * T_ * HD + h * D;
+
+    v8 qf[C::QT][C::NDC], gf[C::QT][C::NDC];
+    float lse2[C::QT], dlt[C::QT];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        const int t = t0 + qt * 16 + x;
+        lse2[qt] = (t < T_) ? lse[(size_t)bh * T_ + t] * LOG2E : 0.f;
+        dlt[qt] = (t < T_) ? delta[(size_t)bh * T_ + t] : 0.f;
+#pragma unroll
+        for (int dc = 0; dc < C::NDC; ++dc) {
+            qf[qt][dc] = buf_load8<T>(rq, row_off<T, C>(t, row_bytes, dc * 32 + g * 8));
+            gf[qt][dc] = buf_load8<T>(rg, row_off<T, C>(t, row_bytes, dc * 32 + g * 8));
+        }
+    }
+    f32x4 acc[C::QT][C::NDB];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) acc[qt][db] = vzero<f32x4>();
+
+    for (int j = 0; j < nkt; ++j) {
+        const int s0 = j * KT;
+        __syncthreads();
+        if constexpr (C::TIMG) stage_rowmajor_image<T, C>(Ki, kb + (size_t)s0 * HD, HD, T_ - s0);
+        else stage_row_image<T, C>(Ki, kb + (size_t)s0 * HD, HD, T_ - s0);
+        stage_row_image<T, C>(Vf, vb + (size_t)s0 * HD, HD, T_ - s0);
+        for (int i = threadIdx.x; i < KT; i += blockDim.x) vld[i] = (s0 + i < T_) ? valid[(size_t)b * T_ + s0 + i] : 0;
+        __syncthreads();
+        if (s0 > t0 + TILE - 1) continue;
+
+        f32x4 bias[4];
+        tile_bias<C>(vld, g, bias);
+        const bool diag = s0 + KT - 1 > t0;
+        v8 dsf[C::QT][2];
+        {
+            f32x4 sacc[C::QT][4], pacc[C::QT][4];
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt) { sacc[qt][sb] = bias[sb]; pacc[qt][sb] = vzero<f32x4>(); }
+#pragma unroll
+                for (int dc = 0; dc < C::NDC; ++dc) {
+                    v8 kf;
+                    if constexpr (C::TIMG) kf = rm_rowfrag<T, C>(Ki, sb, dc, lane);
+                    else kf = *(const v8*)(Ki + rf_idx<C>(sb, dc, lane));
+                    const v8 vf = *(const v8*)(Vf + rf_idx<C>(sb, dc, lane));
+#pragma unroll
+                    for (int qt = 0; qt < C::QT; ++qt) {
+                        mma16(sacc[qt][sb], kf, qf[qt][dc]);
+                        mma16(pacc[qt][sb], vf, gf[qt][dc]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int qt = 0; qt < C::QT; ++qt) {
+                const int t = t0 + qt * 16 + x;
+#pragma unroll
+                for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float sc = sacc[qt][sb][r];
+                        if (diag && (s0 + sb * 16 + g * 4 + r > t)) sc = -INFINITY;
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sc, LOG2E, -lse2[qt]));
+                        sacc[qt][sb][r] = p * (pacc[qt][sb][r] - dlt[qt]);
+                    }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) dsf[qt][ks] = pack8<T>(sacc[qt][2 * ks], sacc[qt][2 * ks + 1]);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                v8 kt;
+                if constexpr (C::TIMG) kt = rm_tfrag_tr16<C>(Ki, db, ks, lane);
+                else kt = load_tfrag<T, C>(Ki, Ki, db, ks, lane);
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt) mma16(acc[qt][db], kt, dsf[qt][ks]);
+            }
+    }
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        const int t = t0 + qt * 16 + x;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) buf_store4<T>(rd, row_off<T, C>(t, row_bytes, db * 16 + g * 4), acc[qt][db]);
+    }
+}
+
+// ============================================================================================ backward: dK, dV
+// Workgroup = (b, h, 64-key tile); wave w: key half (w>>1) of 32 keys, query tiles of parity (w&1).  Non-swapped products:
+// lane = key column, P / dS leave the accumulators in B-operand layout for the contraction over t; Q^T / dO^T come
+// from a wave-private row-major LDS tile via tr16 (bf16) or scalar gathers (f32).  The two parity waves of a key half
+// are folded through LDS at the end: every dK / dV element is written exactly once (deterministic, no partials).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void selfattn_bwd_dkv_kernel(const T* __restrict__ dout, const T* __restrict__ q,
+                                                               const T* __restrict__ k, const T* __restrict__ v,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               const uint8_t* __restrict__ valid, T* __restrict__ dk,
+                                                               T* __restrict__ dv, int B, int H, int T_, int nkb) {
+    typedef XC<T, D, 2> C;                         // one wave's key group: 32 keys = 2 blocks
+    typedef typename Elem<T>::v8 v8;
+    constexpr int LDT = C::DPAD + 16;              // row stride of the wave-private tiles (elements)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Kb = (T*)smem;                              // [2 halves][ROWIMG]
+    T* Vb = Kb + 2 * C::ROWIMG;
+    T* tiles = Vb + 2 * C::ROWIMG;                 // [4 waves][2 (Q, dO)][32 * LDT]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = lane & 15, g = lane >> 4;
+    const int half = wave >> 1, par = wave & 1;
+    T* Qt = tiles + (size_t)wave * 2 * 32 * LDT;
+    T* Gt = Qt + 32 * LDT;
+
+    const int vid = xcd_remap(blockIdx.x, B * H * nkb);
+    const int bh = vid / nkb, kblk = vid % nkb;                 // low key tiles (most query tiles) first
+    const int b = bh / H, h = bh % H;
+    const size_t HD = (size_t)H * D;
+    const int s0 = kblk * KT + half * 32;
+    const T* kb = k + ((size_t)b * T_ + kblk * KT) * HD + h * D;
+    const T* vb = v + ((size_t)b * T_ + kblk * KT) * HD + h * D;
+
+    // stage both halves' K / V row fragments (64 keys): image `half` holds keys [32 half, 32 half + 32)
+    for (int hh = 0; hh < 2; ++hh) {
+        stage_row_image<T, C>(Kb + hh * C::ROWIMG, kb + (size_t)hh * 32 * HD, HD, T_ - (kblk * KT + hh * 32));
+        stage_row_image<T, C>(Vb + hh * C::ROWIMG, vb + (size_t)hh * 32 * HD, HD, T_ - (kblk * KT + hh * 32));
+    }
+    bool vs[2];
+#pragma unroll
+    for (int sbl = 0; sbl < 2; ++sbl) {
+        const int s = s0 + sbl * 16 + x;
+        vs[sbl] = s < T_ && valid[(size_t)b * T_ + s] != 0;
+    }
+    __syncthreads();
+    const T* Kh = Kb + half * C::ROWIMG;
+    const T* Vh = Vb + half * C::ROWIMG;
+
+    f32x4 dva[C::NDB][2], dka[C::NDB][2];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int sbl = 0; sbl < 2; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
+
+    const T* qb = q + (size_t)b * T_ * HD + h * D;
+    const T* gb = dout + (size_t)b * T_ * HD + h * D;
+    const float* lb = lse + (size_t)bh * T_;
+    const float* dlb = delta + (size_t)bh * T_;
+    const int tfirst = (s0 / 32) * 32;                          // first 32-row query tile that can see key s0
+
+    for (int t0 = tfirst + par * 32; t0 < T_; t0 += 64) {
+        v8 qa[2][C::NDC], ga[2][C::NDC];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc) {
+                const int t = t0 + tb * 16 + x;
+                qa[tb][dc] = load_qfrag<T, C>(qb, t, T_, HD, dc * 32 + g * 8);
+                ga[tb][dc] = load_qfrag<T, C>(gb, t, T_, HD, dc * 32 + g * 8);
+                *(v8*)(Qt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = qa[tb][dc];
+                *(v8*)(Gt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = ga[tb][dc];
+            }
+        const bool diag = t0 < s0 + 31;                         // some (row, key) pair with key > row
+        f32x4 pr[2][2], dsr[2][2];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            float lt[4], dt[4];
+            bool tv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + tb * 16 + g * 4 + r;
+                tv[r] = t < T_;
+                lt[r] = tv[r] ? lb[t] * LOG2E : 0.f;
+                dt[r] = tv[r] ? dlb[t] : 0.f;
+            }
+#pragma unroll
+            for (int sbl = 0; sbl < 2; ++sbl) {
+                f32x4 sa = vzero<f32x4>(), pa = vzero<f32x4>();
+#pragma unroll
+                for (int dc = 0; dc < C::NDC; ++dc) {
+                    const v8 kf = *(const v8*)(Kh + rf_idx<C>(sbl, dc, lane));
+                    const v8 vf = *(const v8*)(Vh + rf_idx<C>(sbl, dc, lane));
+                    mma16(sa, qa[tb][dc], kf);
+                    mma16(pa, ga[tb][dc], vf);
+                }
+                const int s = s0 + sbl * 16 + x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = t0 + tb * 16 + g * 4 + r;
+                    const bool ok = tv[r] && vs[sbl] && (!diag || s <= t);
+                    const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sa[r], LOG2E, -lt[r])) : 0.f;
+                    pr[tb][sbl][r] = p;
+                    dsr[tb][sbl][r] = p * (pa[r] - dt[r]);
+                }
+            }
+        }
+        v8 pB[2], dsB[2];
+#pragma unroll
+        for (int sbl = 0; sbl < 2; ++sbl) {
+            pB[sbl] = pack8<T>(pr[0][sbl], pr[1][sbl]);
+            dsB[sbl] = pack8<T>(dsr[0][sbl], dsr[1][sbl]);
+        }
+        // wave-private tiles: LDS ops of one wave execute in order; the fence only stops compiler reordering
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) {
+            v8 gT, qT;
+            if constexpr (sizeof(T) == 2) {
+                typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+                const int i = lane & 15;
+                const bf16* pg = (const bf16*)Gt + (4 * g + (i >> 2)) * LDT + db * 16 + (i & 3) * 4;
+                const bf16* pq = (const bf16*)Qt + (4 * g + (i >> 2)) * LDT + db * 16 + (i & 3) * 4;
+                const bf16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pg);
+                const bf16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pg + 16 * LDT));
+                const bf16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pq);
+                const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pq + 16 * LDT));
+                gT = bf16x8{g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                qT = bf16x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int row = (e >> 2) * 16 + g * 4 + (e & 3);
+                    gT[e] = Gt[row * LDT + db * 16 + x];
+                    qT[e] = Qt[row * LDT + db * 16 + x];
+                }
+            }
+#pragma unroll
+            for (int sbl = 0; sbl < 2; ++sbl) {
+                mma16(dva[db][sbl], gT, pB[sbl]);
+                mma16(dka[db][sbl], qT, dsB[sbl]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // fold the two query-parity waves of each key half through LDS (reuse the tile region), then store
+    __syncthreads();
+    float* red = (float*)tiles;                                // [2 halves][NDB][2][64 lanes][4] floats x 2 (dk, dv)
+    const int per = C::NDB * 2 * 64 * 4;
+    if (par == 1) {
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int sbl = 0; sbl < 2; ++sbl) {
+                *(f32x4*)(red + (size_t)half * 2 * per + ((db * 2 + sbl) * 64 + lane) * 4) = dka[db][sbl];
+                *(f32x4*)(red + (size_t)half * 2 * per + per + ((db * 2 + sbl) * 64 + lane) * 4) = dva[db][sbl];
+            }
+    }
+    __syncthreads();
+    if (par == 0) {
+#pragma unroll
+        for (int sbl = 0; sbl < 2; ++sbl) {
+            const int s = s0 + sbl * 16 + x;
+            if (s < T_) {
+                const size_t off = ((size_t)b * T_ + s) * HD + h * D + g * 4;
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) {
+                    const f32x4 a = dka[db][sbl] + *(const f32x4*)(red + (size_t)half * 2 * per + ((db * 2 + sbl) * 64 + lane) * 4);
+                    const f32x4 c = dva[db][sbl] + *(const f32x4*)(red + (size_t)half * 2 * per + per + ((db * 2 + sbl) * 64 + lane) * 4);
+                    store4<T>(dk + off + db * 16, a);
+                    store4<T>(dv + off + db * 16, c);
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================================ host
+template <typename K> int set_lds_sa(K kern, size_t bytes) {
+    if (bytes > 160 * 1024) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "selfattn: needs %zu B of LDS (> 160 KiB)", bytes);
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    return MMGL_OK;
+}
+
+template <typename T, int D>
+int sa_fwd(const void* q, const void* k, const void* v, const uint8_t* valid, void* out, float* lse, int B, int H, int T_,
+           hipStream_t st) {
+    typedef SC<T, D> C;
+    const int QB = 4 * 16 * C::QT, nqb = cdiv(T_, QB);
+    const size_t lds = sizeof(T) * (C::ROWIMG + (C::TIMG ? C::RMIMG : C::ROWIMG)) + KT;
+    auto kern = selfattn_fwd_kernel<T, D>;
+    int rc = set_lds_sa(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(B * H * nqb), dim3(256), lds, st, (const T*)q, (const T*)k, (const T*)v, valid, (T*)out, lse, B, H,
+                       T_, nqb);
+    MMGL_CHECK_LAUNCH("selfattn_fwd");
+    return MMGL_OK;
+}
+
+template <typename T, int D>
+int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, const uint8_t* valid,
+           void* dq, void* dk, void* dv, float* delta, int B, int H, int T_, hipStream_t st) {
+    {
+        const size_t total = (size_t)B * T_ * H * (D / 8);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL((rowdot_kernel<T, D>), dim3(blocks), dim3(256), 0, st, (const T*)dout, (const T*)out, delta, B, H, T_);
+        MMGL_CHECK_LAUNCH("selfattn_rowdot");
+    }
+    {
+        typedef XC<T, D, 4, 2> C;
+        const int QB = 4 * 16 * C::QT, nqb = cdiv(T_, QB);
+        const size_t lds = sizeof(T) * ((C::TIMG ? C::RMIMG : C::ROWIMG) + C::ROWIMG) + KT;
+        auto kern = selfattn_bwd_dq_kernel<T, D>;
+        int rc = set_lds_sa(kern, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(B * H * nqb), dim3(256), lds, st, (const T*)dout, (const T*)q, (const T*)k, (const T*)v, lse,
+                           delta, valid, (T*)dq, B, H, T_, nqb);
+        MMGL_CHECK_LAUNCH("selfattn_bwd_dq");
+    }
+    {
+        typedef XC<T, D, 2> C;
+        constexpr int LDT = C::DPAD + 16;
+        const int nkb = cdiv(T_, KT);
+        size_t tiles = sizeof(T) * 4 * 2 * 32 * LDT;
+        const size_t red = sizeof(float) * 2 * 2 * (C::NDB * 2 * 64 * 4);
+        if (red > tiles) tiles = red;
+        const size_t lds = sizeof(T) * 4 * C::ROWIMG + tiles;
+        auto kern = selfattn_bwd_dkv_kernel<T, D>;
+        int rc = set_lds_sa(kern, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(B * H * nkb), dim3(256), lds, st, (const T*)dout, (const T*)q, (const T*)k, (const T*)v, lse,
+                           delta, valid, (T*)dk, (T*)dv, B, H, T_, nkb);
+        MMGL_CHECK_LAUNCH("selfattn_bwd_dkv");
+    }
+    return MMGL_OK;
+}
+
+int sa_check(const char* who, int B, int H, int T, int D, int dtype) {
+    MMGL_CHECK_ARG(B > 0 && H > 0 && T > 0, "%s: B,H,T must be positive (got %d,%d,%d)", who, B, H, T);
+    MMGL_CHECK_ARG(dtype == MMGL_F32 || dtype == MMGL_BF16, "%s: dtype must be MMGL_F32 or MMGL_BF16", who);
+    if (!(D == 16 || D == 32 || D == 64 || D == 128)) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "%s: head_dim %d not in {16,32,64,128}", who, D);
+    return MMGL_OK;
+}
+
+#define SA_DISPATCH(FN, T, ...)                        \
+    switch (D) {                                       \
+        case 16: return FN<T, 16>(__VA_ARGS__);        \
+        case 32: return FN<T, 32>(__VA_ARGS__);        \
+        case 64: return FN<T, 64>(__VA_ARGS__);        \
+        default: return FN<T, 128>(__VA_ARGS__);       \
+    }
+
+}  // namespace
+
+extern "C" int mmgl_selfattn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out, float* lse,
+                                 int B, int H, int T, int D, int dtype, void* stream) {
+    int rc = sa_check("mmgl_selfattn_fwd", B, H, T, D, dtype);
+    if (rc) return rc;
+    MMGL_CHECK_ARG(q && k && v && key_valid && out && lse, "mmgl_selfattn_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMGL_BF16) { SA_DISPATCH(sa_fwd, bf16, q, k, v, key_valid, out, lse, B, H, T, st) }
+    SA_DISPATCH(sa_fwd, float, q, k, v, key_valid, out, lse, B, H, T, st)
+}
+
+extern "C" size_t mmgl_selfattn_bwd_workspace(int B, int H, int T) {
+    if (B <= 0 || H <= 0 || T <= 0) return 0;
+    return align_up((size_t)B * H * T * sizeof(float), 256);
+}
+
+extern "C" int mmgl_selfattn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse,
+                                 const uint8_t* key_valid, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
+                                 int B, int H, int T, int D, int dtype, void* stream) {
+    int rc = sa_check("mmgl_selfattn_bwd", B, H, T, D, dtype);
+    if (rc) return rc;
+    MMGL_CHECK_ARG(dout && q && k && v && out && lse && key_valid && dq && dk && dv && workspace, "mmgl_selfattn_bwd: null pointer");
+    MMGL_CHECK_ARG(workspace_bytes >= mmgl_selfattn_bwd_workspace(B, H, T), "mmgl_selfattn_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* delta = (float*)workspace;
+    if (dtype == MMGL_BF16) { SA_DISPATCH(sa_bwd, bf16, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, st) }
+    SA_DISPATCH(sa_bwd, float, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, st)
+}

@@ -59,6 +59,52 @@ def xattn_core(q, k, v, key_valid, num_heads):
     return _XAttnCore.apply(q, k, v, key_valid.contiguous(), num_heads)
 
 
+# ------------------------------------------------------------------------------------------ causal self-attention
+class _SelfAttnCore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, key_valid, num_heads):
+        require_cuda(q, k, v, key_valid)
+        B, T, d = q.shape
+        D = d // num_heads
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out = torch.empty_like(q)
+        lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=q.device)
+        _lib.call("mmgl_selfattn_fwd", dict(flops=2.0 * B * T * T * d, bytes=4.0 * B * T * d * q.element_size()),
+                  ptr(q), ptr(k), ptr(v), ptr(key_valid), ptr(out), ptr(lse), B, num_heads, T, D, dtype_code(q), stream_ptr())
+        ctx.save_for_backward(q, k, v, key_valid, out, lse)
+        ctx.num_heads = num_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, key_valid, out, lse = ctx.saved_tensors
+        H = ctx.num_heads
+        B, T, d = q.shape
+        D = d // H
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        nbytes = lib().mmgl_selfattn_bwd_workspace(B, H, T)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        _lib.call("mmgl_selfattn_bwd", dict(flops=5.0 * B * T * T * d, bytes=8.0 * B * T * d * q.element_size()),
+                  ptr(dout), ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(key_valid), ptr(dq), ptr(dk), ptr(dv), ptr(ws), nbytes,
+                  B, H, T, D, dtype_code(q), stream_ptr())
+        return dq, dk, dv, None, None
+
+
+def selfattn_core(q, k, v, key_valid, num_heads):
+    """Causal self-attention softmax(mask(q k^T)) v with mask = (s <= t) & key_valid[b, s]; q is already scaled.
+    The caller guarantees key_valid[:, 0] is all ones (see include/mmgl_hip.h).  (reference :203-271 self branch)"""
+    if q.dim() != 3 or q.shape != k.shape or k.shape != v.shape:
+        raise ValueError(f"selfattn_core: incompatible shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+    if q.shape[2] % num_heads:
+        raise ValueError(f"embed_dim must be divisible by num_heads (got `embed_dim`: {q.shape[2]} and `num_heads`: {num_heads}).")
+    if key_valid.shape != q.shape[:2]:
+        raise ValueError(f"Attention mask should be of size {tuple(q.shape[:2])}, but is {tuple(key_valid.shape)}")
+    if key_valid.dtype != torch.uint8:
+        key_valid = key_valid.to(torch.uint8)
+    return _SelfAttnCore.apply(q, k, v, key_valid.contiguous(), num_heads)
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
