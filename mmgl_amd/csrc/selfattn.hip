@@ -305,8 +305,8 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
 // lane = key column, P / dS leave the accumulators in B-operand layout for the contraction over t; Q^T / dO^T come
 // from a wave-private row-major LDS tile via tr16 (bf16) or scalar gathers (f32).  The two parity waves of a key half
 // are folded through LDS at the end: every dK / dV element is written exactly once (deterministic, no partials).
-template <typename T, int D>
-__global__ __launch_bounds__(256) void selfattn_bwd_dkv_kernel(const T* __restrict__ dout, const T* __restrict__ q,
+template <typename T, int D, int PAR>
+__global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __restrict__ dout, const T* __restrict__ q,
                                                                const T* __restrict__ k, const T* __restrict__ v,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                const uint8_t* __restrict__ valid, T* __restrict__ dk,
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dkv_kernel(const T* __restri
     T* tiles = Vb + 2 * C::ROWIMG;                 // [4 waves][2 (Q, dO)][32 * LDT]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = lane & 15, g = lane >> 4;
-    const int half = wave >> 1, par = wave & 1;
+    const int half = wave / PAR, par = wave % PAR;           // PAR = 1: two waves, one per key half (fp32 D = 128: LDS budget)
     T* Qt = tiles + (size_t)wave * 2 * 32 * LDT;
     T* Gt = Qt + 32 * LDT;
 
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dkv_kernel(const T* __restri
     const float* dlb = delta + (size_t)bh * T_;
     const int tfirst = (s0 / 32) * 32;                          // first 32-row query tile that can see key s0
 
-    for (int t0 = tfirst + par * 32; t0 < T_; t0 += 64) {
+    for (int t0 = tfirst + par * 32; t0 < T_; t0 += 32 * PAR) {
         v8 qa[2][C::NDC], ga[2][C::NDC];
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dkv_kernel(const T* __restri
     __syncthreads();
     float* red = (float*)tiles;                                // [2 halves][NDB][2][64 lanes][4] floats x 2 (dk, dv)
     const int per = C::NDB * 2 * 64 * 4;
-    if (par == 1) {
+    if (PAR == 2 && par == 1) {
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
@@ -468,8 +468,11 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dkv_kernel(const T* __restri
                 const size_t off = ((size_t)b * T_ + s) * HD + h * D + g * 4;
 #pragma unroll
                 for (int db = 0; db < C::NDB; ++db) {
-                    const f32x4 a = dka[db][sbl] + *(const f32x4*)(red + (size_t)half * 2 * per + ((db * 2 + sbl) * 64 + lane) * 4);
-                    const f32x4 c = dva[db][sbl] + *(const f32x4*)(red + (size_t)half * 2 * per + per + ((db * 2 + sbl) * 64 + lane) * 4);
+                    f32x4 a = dka[db][sbl], c = dva[db][sbl];
+                    if (PAR == 2) {
+                        a += *(const f32x4*)(red + (size_t)half * 2 * per + ((db * 2 + sbl) * 64 + lane) * 4);
+                        c += *(const f32x4*)(red + (size_t)half * 2 * per + per + ((db * 2 + sbl) * 64 + lane) * 4);
+                    }
                     store4<T>(dk + off + db * 16, a);
                     store4<T>(dv + off + db * 16, c);
                 }
@@ -528,15 +531,25 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
         typedef XC<T, D, 2> C;
         constexpr int LDT = C::DPAD + 16;
         const int nkb = cdiv(T_, KT);
-        size_t tiles = sizeof(T) * 4 * 2 * 32 * LDT;
         const size_t red = sizeof(float) * 2 * 2 * (C::NDB * 2 * 64 * 4);
-        if (red > tiles) tiles = red;
-        const size_t lds = sizeof(T) * 4 * C::ROWIMG + tiles;
-        auto kern = selfattn_bwd_dkv_kernel<T, D>;
-        int rc = set_lds_sa(kern, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3(B * H * nkb), dim3(256), lds, st, (const T*)dout, (const T*)q, (const T*)k, (const T*)v, lse,
-                           delta, valid, (T*)dk, (T*)dv, B, H, T_, nkb);
+        auto lds_for = [&](int par) {
+            size_t tiles = sizeof(T) * (2 * par) * 2 * 32 * LDT;
+            if (par == 2 && red > tiles) tiles = red;
+            return sizeof(T) * 4 * C::ROWIMG + tiles;
+        };
+        if (lds_for(2) <= 160 * 1024) {
+            auto kern = selfattn_bwd_dkv_kernel<T, D, 2>;
+            int rc = set_lds_sa(kern, lds_for(2));
+            if (rc) return rc;
+            hipLaunchKernelGGL(kern, dim3(B * H * nkb), dim3(256), lds_for(2), st, (const T*)dout, (const T*)q, (const T*)k, (const T*)v,
+                               lse, delta, valid, (T*)dk, (T*)dv, B, H, T_, nkb);
+        } else {
+            auto kern = selfattn_bwd_dkv_kernel<T, D, 1>;
+            int rc = set_lds_sa(kern, lds_for(1));
+            if (rc) return rc;
+            hipLaunchKernelGGL(kern, dim3(B * H * nkb), dim3(128), lds_for(1), st, (const T*)dout, (const T*)q, (const T*)k, (const T*)v,
+                               lse, delta, valid, (T*)dk, (T*)dv, B, H, T_, nkb);
+        }
         MMGL_CHECK_LAUNCH("selfattn_bwd_dkv");
     }
     return MMGL_OK;
