@@ -157,14 +157,20 @@ class MPTAttention(nn.Module):
     def _forward_self(self, hidden_states, attention_mask, layer_head_mask, output_attentions):
         bsz, tgt_len, _ = hidden_states.shape
         H, D = self.num_heads, self.head_dim
+        if attention_mask is not None and attention_mask.dim() == 2:
+            # [B,T] key-valid mask, causal implied: the HIP flash kernels (mmgl_selfattn_fwd/bwd) -- no [B,1,T,T] mask, no
+            # [B,H,T,T] scores, no head transposes.  MPTDecoder only hands this form over when key 0 of every sample is valid.
+            if layer_head_mask is not None or output_attentions or (self.training and self.dropout > 0):
+                raise ValueError("layer_head_mask / output_attentions / attention dropout need the unfused self-attention path")
+            q = self.q_proj(hidden_states) * self.scaling
+            o = ops.selfattn_core(q, self.k_proj(hidden_states), self.v_proj(hidden_states), attention_mask, H)
+            return self.out_proj(o), None, None
         q = (self.q_proj(hidden_states) * self.scaling).view(bsz, tgt_len, H, D).transpose(1, 2)
         k = self.k_proj(hidden_states).view(bsz, tgt_len, H, D).transpose(1, 2)
         v = self.v_proj(hidden_states).view(bsz, tgt_len, H, D).transpose(1, 2)
         if (self.fused_self_attention and attention_mask is not None and attention_mask.dtype == torch.bool
                 and layer_head_mask is None and not output_attentions and not (self.training and self.dropout > 0)):
-            # interim for the frozen layers (not yet a HIP kernel of this repo): torch's fused SDPA with
-            # the boolean (causal & key-valid) mask.  Same softmax as the additive finfo.min mask + clamp whenever a query
-            # row keeps at least one key, which MPTDecoder guarantees before it builds a boolean mask.
+            # torch's fused SDPA with the boolean (causal & key-valid) mask: kept as an alternative backend
             o = F.scaled_dot_product_attention(q, k, v, attn_mask=attention_mask, scale=1.0)
             o = o.transpose(1, 2).reshape(bsz, tgt_len, self.embed_dim)
             return self.out_proj(o), None, None
@@ -372,11 +378,14 @@ class MPTDecoder(MPTPreTrainedModel):
                              f"{seq_length} (sum of the lengths of current and past inputs)")
         causal_attention_mask = self._prepare_decoder_attention_mask(attention_mask, input_shape, inputs_embeds, 0)
         if (self.fused_self_attention and not output_attentions and head_mask is None and self.config.attention_dropout == 0
-                and seq_length > 1 and bool((attention_mask[:, 0] != 0).all())):
-            # every query row keeps key 0 (sequences are right-padded, data.py:321-333), so no row is fully masked and the
-            # boolean (causal & key-valid) mask is equivalent to the additive one; [B,1,T,T] bool = 1/2..1/4 the bytes
-            keep = torch.ones(seq_length, seq_length, dtype=torch.bool, device=inputs_embeds.device).tril_()
-            causal_attention_mask = keep[None, None] & (attention_mask[:, None, None, :] != 0)
+                and seq_length > 1 and inputs_embeds.is_cuda and bool((attention_mask[:, 0] != 0).all())):
+            # every query row keeps key 0 (sequences are right-padded, data.py:321-333), so no row is fully masked and
+            # (causal & key-valid) is equivalent to the additive finfo.min masks: hand the [B,T] mask to the flash kernels
+            if self.fused_self_attention == "sdpa":
+                keep = torch.ones(seq_length, seq_length, dtype=torch.bool, device=inputs_embeds.device).tril_()
+                causal_attention_mask = keep[None, None] & (attention_mask[:, None, None, :] != 0)
+            else:
+                causal_attention_mask = (attention_mask != 0).to(torch.uint8).contiguous()
         key_valid = None
         if neighbor_attention_mask is not None:
             key_valid = _key_valid_from(neighbor_attention_mask).to(torch.uint8).contiguous()
