@@ -25,6 +25,37 @@ template <typename C> __device__ __forceinline__ void tile_bias(const uint8_t* v
     }
 }
 
+
+// Register-staged K / V tile (T14 split: the next tile's global loads are issued before the current tile's MFMAs and
+// written to LDS after them, so the HBM/L2 latency of a 64-key tile hides under compute).
+template <typename T, typename C, bool K_ROWMAJOR, bool V_ROWMAJOR> struct TileStage {
+    typedef typename Elem<T>::v8 v8;
+    static constexpr int N = C::SPAD * C::CPR / 256;          // chunks per thread per operand (256 threads)
+    v8 kr[N], vr[N];
+    uint8_t vb;
+    __device__ __forceinline__ void load(const T* kbase, const T* vbase, const uint8_t* valid_row, size_t row_stride, int s0, int T_) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int id = threadIdx.x + i * 256, s = id / C::CPR, c = id % C::CPR;
+            const bool ok = (s0 + s < T_) && (c * 8 < C::D);
+            kr[i] = ok ? *(const v8*)(kbase + (size_t)(s0 + s) * row_stride + c * 8) : vzero<v8>();
+            vr[i] = ok ? *(const v8*)(vbase + (size_t)(s0 + s) * row_stride + c * 8) : vzero<v8>();
+        }
+        vb = (threadIdx.x < KT && s0 + (int)threadIdx.x < T_) ? valid_row[s0 + threadIdx.x] : 0;
+    }
+    __device__ __forceinline__ void store(T* Kimg, T* Vimg, uint8_t* vld) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int id = threadIdx.x + i * 256, s = id / C::CPR, c = id % C::CPR;
+            if constexpr (K_ROWMAJOR) *(v8*)(Kimg + s * C::LD + c * 8) = kr[i];
+            else *(v8*)(Kimg + rf_idx<C>(s >> 4, c >> 2, (s & 15) + 16 * (c & 3))) = kr[i];
+            if constexpr (V_ROWMAJOR) *(v8*)(Vimg + s * C::LD + c * 8) = vr[i];
+            else *(v8*)(Vimg + rf_idx<C>(s >> 4, c >> 2, (s & 15) + 16 * (c & 3))) = vr[i];
+        }
+        if (threadIdx.x < KT) vld[threadIdx.x] = vb;
+    }
+};
+
 // ============================================================================================ forward
 template <typename T, int D>
 __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
@@ -72,15 +103,14 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
         for (int db = 0; db < C::NDB; ++db) oacc[qt][db] = vzero<f32x4>();
     }
 
+    TileStage<T, C, false, C::TIMG> stg;
+    stg.load(kb, vb, valid + (size_t)b * T_, HD, 0, T_);
+    stg.store(Kf, Vi, vld);
+    __syncthreads();
     for (int j = 0; j < nkt; ++j) {
         const int s0 = j * KT;
-        __syncthreads();
-        stage_row_image<T, C>(Kf, kb + (size_t)s0 * HD, HD, T_ - s0);
-        if constexpr (C::TIMG) stage_rowmajor_image<T, C>(Vi, vb + (size_t)s0 * HD, HD, T_ - s0);
-        else stage_row_image<T, C>(Vi, vb + (size_t)s0 * HD, HD, T_ - s0);
-        for (int i = threadIdx.x; i < KT; i += blockDim.x) vld[i] = (s0 + i < T_) ? valid[(size_t)b * T_ + s0 + i] : 0;
-        __syncthreads();
-        if (s0 > t0 + TILE - 1) continue;                     // tile entirely above this wave's diagonal (wave-uniform)
+        if (j + 1 < nkt) stg.load(kb, vb, valid + (size_t)b * T_, HD, s0 + KT, T_);
+        if (s0 <= t0 + TILE - 1) {                            // else: tile entirely above this wave's diagonal (wave-uniform)
 
         f32x4 bias[4];
         tile_bias<C>(vld, g, bias);
@@ -142,6 +172,10 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
 #pragma unroll
                 for (int qt = 0; qt < C::QT; ++qt) mma16(oacc[qt][db], vt, pf[qt][ks]);
             }
+        }
+        __syncthreads();                                      // every wave is done reading tile j
+        if (j + 1 < nkt) stg.store(Kf, Vi, vld);
+        __syncthreads();
     }
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
@@ -232,15 +266,14 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db) acc[qt][db] = vzero<f32x4>();
 
+    TileStage<T, C, C::TIMG, false> stg;
+    stg.load(kb, vb, valid + (size_t)b * T_, HD, 0, T_);
+    stg.store(Ki, Vf, vld);
+    __syncthreads();
     for (int j = 0; j < nkt; ++j) {
         const int s0 = j * KT;
-        __syncthreads();
-        if constexpr (C::TIMG) stage_rowmajor_image<T, C>(Ki, kb + (size_t)s0 * HD, HD, T_ - s0);
-        else stage_row_image<T, C>(Ki, kb + (size_t)s0 * HD, HD, T_ - s0);
-        stage_row_image<T, C>(Vf, vb + (size_t)s0 * HD, HD, T_ - s0);
-        for (int i = threadIdx.x; i < KT; i += blockDim.x) vld[i] = (s0 + i < T_) ? valid[(size_t)b * T_ + s0 + i] : 0;
-        __syncthreads();
-        if (s0 > t0 + TILE - 1) continue;
+        if (j + 1 < nkt) stg.load(kb, vb, valid + (size_t)b * T_, HD, s0 + KT, T_);
+        if (s0 <= t0 + TILE - 1) {
 
         f32x4 bias[4];
         tile_bias<C>(vld, g, bias);
@@ -291,6 +324,10 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
 #pragma unroll
                 for (int qt = 0; qt < C::QT; ++qt) mma16(acc[qt][db], kt, dsf[qt][ks]);
             }
+        }
+        __syncthreads();
+        if (j + 1 < nkt) stg.store(Ki, Vf, vld);
+        __syncthreads();
     }
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
@@ -359,15 +396,26 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
     const float* dlb = delta + (size_t)bh * T_;
     const int tfirst = (s0 / 32) * 32;                          // first 32-row query tile that can see key s0
 
+    v8 qn[2][C::NDC], gn[2][C::NDC];                         // next tile's fragments, in flight during this tile's MFMAs
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int dc = 0; dc < C::NDC; ++dc) {
+            const int t = tfirst + par * 32 + tb * 16 + x;
+            qn[tb][dc] = load_qfrag<T, C>(qb, t, T_, HD, dc * 32 + g * 8);
+            gn[tb][dc] = load_qfrag<T, C>(gb, t, T_, HD, dc * 32 + g * 8);
+        }
     for (int t0 = tfirst + par * 32; t0 < T_; t0 += 32 * PAR) {
         v8 qa[2][C::NDC], ga[2][C::NDC];
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
             for (int dc = 0; dc < C::NDC; ++dc) {
-                const int t = t0 + tb * 16 + x;
-                qa[tb][dc] = load_qfrag<T, C>(qb, t, T_, HD, dc * 32 + g * 8);
-                ga[tb][dc] = load_qfrag<T, C>(gb, t, T_, HD, dc * 32 + g * 8);
+                qa[tb][dc] = qn[tb][dc];
+                ga[tb][dc] = gn[tb][dc];
+                const int tn = t0 + 32 * PAR + tb * 16 + x;
+                qn[tb][dc] = load_qfrag<T, C>(qb, tn, T_, HD, dc * 32 + g * 8);
+                gn[tb][dc] = load_qfrag<T, C>(gb, tn, T_, HD, dc * 32 + g * 8);
                 *(v8*)(Qt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = qa[tb][dc];
                 *(v8*)(Gt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = ga[tb][dc];
             }
