@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
     const int row = blockIdx.x;
     const T* x = logits + (size_t)row * V_;
     float m = -INFINITY, s = 0.f;
-    const int nvec = V_ / VN;
+    const int nvec = (((size_t)V_ * sizeof(T)) % 16 == 0) ? V_ / VN : 0;      // odd vocab sizes: rows are not 16-B aligned -> scalar path
     for (int i = threadIdx.x; i < nvec; i += 256) {
         const V v = ((const V*)x)[i];
         float lm = (float)v[0];
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
     const bool ign = (lab == ignore || lab < 0 || lab >= V_);
     const float scale = ign ? 0.f : (*dloss) / fmaxf(*count, 1.f);
     const float lse = row_lse[row];
-    const int nvec = V_ / VN;
+    const int nvec = (((size_t)V_ * sizeof(T)) % 16 == 0) ? V_ / VN : 0;
     for (int i = threadIdx.x; i < nvec; i += 256) {
         const V v = ((const V*)x)[i];
         V o;
@@ -374,8 +374,6 @@ extern "C" int mmgl_cross_entropy_fwd(const void* logits, const int64_t* labels,
                                       void* stream) {
     MMGL_CHECK_ARG(logits && labels && row_lse && row_loss && loss_sum && count, "mmgl_cross_entropy_fwd: null pointer");
     MMGL_CHECK_ARG(rows > 0 && V > 0, "mmgl_cross_entropy_fwd: bad sizes");
-    const size_t esz = dtype == MMGL_BF16 ? 2 : 4;
-    if (((size_t)V * esz) % 16) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "mmgl_cross_entropy_fwd: vocab rows must be 16-byte multiples");
     hipStream_t st = (hipStream_t)stream;
     BY_DTYPE(hipLaunchKernelGGL(ce_fwd_kernel<bf16>, dim3(rows), dim3(256), 0, st, (const bf16*)logits, labels, row_lse,
                                 row_loss, V, ignore_index),

@@ -137,7 +137,10 @@ def test_self_attention_model_gnn_position_type_runs():
     b["graph"] = g[None].expand(2, -1, -1).contiguous().cuda()
     o = w(**b)
     o.loss.backward()
-    assert torch.isfinite(o.loss) and w.gnn.w1.weight.grad is not None and w.gnn.w1.weight.grad.abs().max() > 0
+    # For a causal LM the neighbors sit AFTER the sequence with labels -100 (reference modelling_self_attention.py:323-330),
+    # so they cannot influence the loss: the GNN gets an exactly-zero gradient (SURVEY.md 3.4 "no-op for causal LMs").
+    assert torch.isfinite(o.loss) and o.logits.shape[1] == b["input_ids"].shape[1] + 5 * 2
+    assert w.gnn.w1.weight.grad is not None and float(w.gnn.w1.weight.grad.abs().max()) == 0.0
 
 
 def test_cli_entry_point_synthetic(tmp_path):
