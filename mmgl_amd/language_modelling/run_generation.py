@@ -201,7 +201,7 @@ def build_model(args, tokenizer, offline=False):
     if "t5" in name:
         args.decoder_only = False
         return SelfAttentionModel(args, tokenizer, **cfgs)
-    if "mpt" in name or ("opt" in name and args.peft_type == "flamingo"):
+    if "mpt" in name or "llama" in name.lower() or ("opt" in name and args.peft_type == "flamingo"):
         args.decoder_only = True
         args.model_name_or_path = name.replace("mpt", "opt")
         return CrossAttentionModel(args, tokenizer, **cfgs)

@@ -634,7 +634,12 @@ class CrossAttentionModel(nn.Module):
             self.lm.train()
 
     def initialize_lm(self, args, lm_config=None):
-        """HF loading API (reference :951-976): OPT weights are copied into the fork layer by layer."""
+        """HF loading API (reference :951-976): OPT weights are copied into the fork layer by layer.  A "llama" model name
+        selects the Llama-family variant (frozen HF LlamaForCausalLM + gated cross-attention layers, no reference counterpart)."""
+        if "llama" in args.model_name_or_path.lower() or (lm_config is not None and getattr(lm_config, "model_type", "") == "llama"):
+            from .modelling_llama_cross_attention import LlamaNeighborLM
+            self.lm = LlamaNeighborLM(args, lm_config)
+            return
         if lm_config is not None:
             opt_config, opt_model = lm_config, None
         else:
