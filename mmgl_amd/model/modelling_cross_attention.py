@@ -560,6 +560,35 @@ def _valid_rows(pos_ids):
     return valid.reshape(-1).nonzero().squeeze(1).to(pos_ids.device)
 
 
+def encode_text_bucketed(text_model, ids, am, n_buckets=4, use_pooler_output=False):
+    """CLS / pooled output of a frozen text encoder over [n, L] right-padded sequences, WITHOUT computing the padding:
+    sequences are sorted by length and encoded in `n_buckets` groups, each truncated to its own longest member (rounded
+    up to 8).  Removing trailing pad keys leaves every softmax unchanged (their weight is exactly 0), so the result equals
+    the padded call up to summation order; the reference pads every neighbor to max_input_length (data.py:457), i.e. ~half
+    of the encoder FLOPs at WikiWeb2M's length spread.  One host sync (the lengths)."""
+    n, L = ids.shape
+    pick = (lambda o: o.pooler_output) if use_pooler_output else (lambda o: o.last_hidden_state[:, 0])
+    if n_buckets <= 1 or n < 2 * n_buckets or L < 64:
+        return pick(text_model(input_ids=ids, attention_mask=am))
+    lens = am.sum(1).clamp_min(1)
+    order = torch.argsort(lens)
+    lens_sorted = lens[order].cpu().tolist()              # host sync
+    out = None
+    start = 0
+    for bkt in range(n_buckets):
+        end = n if bkt == n_buckets - 1 else (n * (bkt + 1)) // n_buckets
+        if end <= start:
+            continue
+        Lb = min(L, (int(lens_sorted[end - 1]) + 7) // 8 * 8)
+        idx = order[start:end]
+        o = pick(text_model(input_ids=ids.index_select(0, idx)[:, :Lb].contiguous(), attention_mask=am.index_select(0, idx)[:, :Lb].contiguous()))
+        if out is None:
+            out = o.new_zeros(n, o.shape[-1])
+        out.index_copy_(0, idx, o)
+        start = end
+    return out
+
+
 class TextPooler(nn.Module):
     """CLS token -> Linear -> tanh (reference :879-893)."""
 
@@ -624,6 +653,7 @@ class CrossAttentionModel(nn.Module):
         # Padded neighbor slots (pos_id 0) are masked keys: they can influence neither the logits nor any gradient, so
         # the frozen encoders skip them (the reference encodes '' texts and all-zero images, data.py:444-454).
         self.skip_padded_neighbors = getattr(args, "skip_padded_neighbors", True)
+        self.text_length_buckets = getattr(args, "text_length_buckets", 4)     # 1 = encode everything padded to L (reference)
 
         if self.args.freeze_lm:
             print("Freezing the LM.")
@@ -678,8 +708,8 @@ class CrossAttentionModel(nn.Module):
         with torch.no_grad():
             if rows is not None:
                 ids, am = ids.index_select(0, rows), am.index_select(0, rows)
-            outputs = self.text_model(input_ids=ids, attention_mask=am)
-            enc = outputs.pooler_output if "clip" in self.args.text_model else outputs.last_hidden_state[:, 0]
+            is_clip = "clip" in self.args.text_model
+            enc = encode_text_bucketed(self.text_model, ids, am, 1 if is_clip else self.text_length_buckets, use_pooler_output=is_clip)
             if rows is not None:
                 full = enc.new_zeros(batch_size * neighbor_num, enc.shape[-1])
                 enc = full.index_copy_(0, rows, enc)
