@@ -24,7 +24,11 @@ template <typename T, int D_, int NSB_, int WORK_ = 1> struct XC {
     static constexpr int NKS = NSB / 2;              // 32-key contraction steps
     static constexpr int SPAD = NSB * 16;
     static constexpr int CPR = DPAD / 8;             // 8-element chunks per (padded) row
+#ifdef MMGL_XATTN_QT_FORCE
+    static constexpr int QT = MMGL_XATTN_QT_FORCE;
+#else
     static constexpr int QT = (WORK_ * NSB_ * (D_ / 16) * (int)(sizeof(T) / 2) <= 32) ? 2 : 1;
+#endif
     static constexpr bool TIMG = (sizeof(T) == 2);   // dedicated transposed image (bf16) vs gather (f32)
     // The K/V operand fragments are loop invariant, so the compiler hoists them into registers when it may
     // (register-resident K/V, no LDS traffic in the loop).  Past this budget that spills: re-read LDS instead.

@@ -30,8 +30,11 @@ namespace {
 // second row image gathered with scalar reads (fp32).  A workgroup covers `rows_per_wg` query rows of one (b, h); its 4
 // waves take 16*QT-row tiles round-robin, and each wave issues the NEXT tile's Q loads before it computes the current
 // one, so every wave keeps HBM requests in flight across its MFMA / softmax / store phases.
+#ifndef MMGL_XATTN_MINWAVES
+#define MMGL_XATTN_MINWAVES 1
+#endif
 template <typename T, int D, int NSB>
-__global__ __launch_bounds__(256) void xattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(256, MMGL_XATTN_MINWAVES) void xattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                         const T* __restrict__ v, const uint8_t* __restrict__ valid,
                                                         T* __restrict__ out, float* __restrict__ lse, int B, int H,
                                                         int T_, int S, int rows_per_wg, int nchunk) {
