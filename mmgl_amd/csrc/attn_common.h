@@ -207,6 +207,23 @@ template <typename T, typename C> __device__ __forceinline__ uint32_t row_off(in
     return o;
 }
 
+// bf16 row-per-lane epilogue: a lane owns 4 consecutive channels (8 B) of each 16-channel block.  Swapping the odd
+// 16-lane rows of block `a` with the even rows of block `b` (= a + 1) leaves every lane with 8 consecutive channels:
+// rows g = 0,2 hold block a's channels 8(g/2)..+7, rows g = 1,3 block b's -- one 16-byte store per lane and 64 contiguous
+// bytes per query row per instruction instead of two 8-byte stores with 32-byte segments.
+__device__ __forceinline__ void swap16_u32(uint32_t& a, uint32_t& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void store_pair_bf16(__amdgpu_buffer_rsrc_t r, uint32_t row_byte_off, int blk_a, int g, bf16x4 va, bf16x4 vb) {
+    u32x2 a = __builtin_bit_cast(u32x2, va), b = __builtin_bit_cast(u32x2, vb);
+    uint32_t a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+    swap16_u32(a0, b0);
+    swap16_u32(a1, b1);
+    const u32x4 v = {a0, a1, b0, b1};
+    const uint32_t off = row_byte_off + (uint32_t)((blk_a + (g & 1)) * 32 + (g >> 1) * 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+}
+
 // reductions across the four 16-lane groups that share a query row: v_permlane16_swap / v_permlane32_swap are plain
 // VALU ops (no LDS round trip like ds_bpermute): swap(v, v) leaves {lower, upper} halves side by side in the two results.
 // NB the two operands must live in DIFFERENT registers (the instruction swaps in place): the empty asm makes the copy

@@ -25,6 +25,20 @@
 
 namespace {
 
+// store one query row's NDB blocks held as 4 channels per lane per block
+template <typename T, typename C>
+__device__ __forceinline__ void store_row_tiles(__amdgpu_buffer_rsrc_t ro, int t, int T_, uint32_t row_bytes, int g,
+                                                const typename Elem<T>::v4 (&o)[C::NDB]) {
+    if constexpr (sizeof(T) == 2 && C::NDB % 2 == 0) {
+        const uint32_t rb = (t < T_) ? (uint32_t)t * row_bytes : 0x80000000u;   // past any slab, and no wrap-around when the column offset is added
+#pragma unroll
+        for (int db = 0; db < C::NDB; db += 2) store_pair_bf16(ro, rb, db, g, o[db], o[db + 1]);
+    } else {
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) buf_store_v4<T>(ro, row_off<T, C>(t, row_bytes, db * 16 + g * 4), o[db]);
+    }
+}
+
 // ============================================================================================ forward
 // LDS: K as a fragment-linear row image; V as a row-major padded image read through ds_read_b64_tr_b16 (bf16) or as a
 // second row image gathered with scalar reads (fp32).  A workgroup covers `rows_per_wg` query rows of one (b, h); its 4
@@ -109,8 +123,7 @@ __global__ __launch_bounds__(256, MMGL_XATTN_MINWAVES) void xattn_fwd_kernel(con
 #pragma unroll
         for (int qt = 0; qt < C::QT; ++qt) {
             const int t = tprev + qt * 16 + x;
-#pragma unroll
-            for (int db = 0; db < C::NDB; ++db) buf_store_v4<T>(ro, row_off<T, C>(t, row_bytes, db * 16 + g * 4), ost[qt][db]);
+            store_row_tiles<T, C>(ro, t, T_, row_bytes, g, ost[qt]);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, lst[qt]), rl, (g == 0) ? (uint32_t)t * 4u : OOB, 0, 0);
         }
         tprev = t0;
@@ -210,8 +223,7 @@ __global__ __launch_bounds__(256, MMGL_XATTN_MINWAVES) void xattn_fwd_kernel(con
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
         const int t = tprev + qt * 16 + x;
-#pragma unroll
-        for (int db = 0; db < C::NDB; ++db) buf_store_v4<T>(ro, row_off<T, C>(t, row_bytes, db * 16 + g * 4), ost[qt][db]);
+        store_row_tiles<T, C>(ro, t, T_, row_bytes, g, ost[qt]);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, lst[qt]), rl, (g == 0) ? (uint32_t)t * 4u : OOB, 0, 0);
     }
 }
