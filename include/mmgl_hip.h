@@ -202,6 +202,25 @@ int mmgl_adamw_step(void* param, float* master, const void* grad, float* exp_avg
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     float grad_scale, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Frozen neighbor encoders, forward only (padding-free RoBERTa / CLIP-ViT passes).
+ * replaces: the HF encoder calls in get_text_embs / get_visual_embs, modelling_cross_attention.py:978-1027
+ * (self.text_model(...), self.visual_model(...)): their attention, residual-add + LayerNorm and activation steps.
+ *
+ * mmgl_encattn_fwd: bidirectional softmax(QK^T)V over PACKED sequences.  Sequence i owns rows
+ *   cu_seqlens[i] .. cu_seqlens[i+1]-1 (int32 device array, nseq+1 entries) of q/k/v [ntok, ld_in] (three column slices
+ *   of a fused-QKV GEMM output are fine: ld_in = 3*H*D) and of out [ntok, ld_out]; head h uses columns h*D..h*D+D-1.
+ *   q must be pre-scaled by D^-1/2.  max_len = longest sequence (host knows it from the packing); q_rows = number of
+ *   leading query rows per sequence to compute (pass max_len for all, 1 for the CLS row only).  No padding token is read.
+ * mmgl_add_layernorm_fwd: s = x + res (rounded to dtype), y = LayerNorm(s); sum_out (may be NULL) receives s.
+ * mmgl_activation_fwd: y = act(x) elementwise, in place allowed; act 1 relu, 2 gelu (erf), 3 quick_gelu, 4 gelu (tanh).
+ */
+int mmgl_encattn_fwd(const void* q, const void* k, const void* v, const int32_t* cu_seqlens, void* out, int nseq,
+                     int H, int D, int ld_in, int ld_out, int max_len, int q_rows, int dtype, void* stream);
+int mmgl_add_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* sum_out,
+                           void* y, int rows, int cols, float eps, int dtype, void* stream);
+int mmgl_activation_fwd(const void* x, void* y, size_t n, int act, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

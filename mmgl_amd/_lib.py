@@ -54,6 +54,9 @@ SIGNATURES = {
     "mmgl_cross_entropy_bwd": (I, [P, P, P, P, P, P, I, I, L, I, P]),
     "mmgl_position_ids": (I, [P, P, I, I, P]),
     "mmgl_adamw_step": (I, [P, P, P, P, P, Z, F, F, F, F, F, I, F, I, P]),
+    "mmgl_encattn_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "mmgl_add_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, I, P]),
+    "mmgl_activation_fwd": (I, [P, P, Z, I, I, P]),
 }
 
 _lib = None

@@ -30,6 +30,31 @@ inline int stream_blocks(size_t nvec) {
     return (int)(b > 2048 ? 2048 : (b ? b : 1));
 }
 
+// ------------------------------------------------------------------------------------------ activation (frozen encoders)
+// One pass over a GEMM output: HF's ACT2FN entries the frozen neighbor encoders use -- RoBERTa "gelu" (erf form),
+// CLIP "quick_gelu" x*sigmoid(1.702x) (three eager kernels in torch), "gelu_new"/"gelu_pytorch_tanh", "relu".
+template <int ACT> __device__ __forceinline__ float act_apply(float a) {
+    if constexpr (ACT == 1) return fmaxf(a, 0.f);
+    else if constexpr (ACT == 2) return 0.5f * a * (1.f + erff(a * 0.70710678118654752440f));
+    else if constexpr (ACT == 3) return a / (1.f + __expf(-1.702f * a));
+    else return 0.5f * a * (1.f + tanhf(0.79788456080286535588f * (a + 0.044715f * a * a * a)));
+}
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n) {
+    typedef typename Vec<T>::type V;
+    constexpr int VN = Vec<T>::N;
+    const size_t nvec = n / VN;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const V xv = ((const V*)x)[i];
+        V o;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) o[j] = (T)act_apply<ACT>((float)xv[j]);
+        ((V*)y)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = nvec * VN; i < n; ++i) y[i] = (T)act_apply<ACT>((float)x[i]);
+}
+
 // ------------------------------------------------------------------------------------------ gated residual
 // y = res + tanh(g) * keep(i) * x / (1-p)        (reference modelling_cross_attention.py:332-335, 356-359)
 template <typename T>
@@ -422,4 +447,26 @@ extern "C" int mmgl_adamw_step(void* param, float* master, const void* grad, flo
              "mmgl_adamw_step");
     MMGL_CHECK_LAUNCH("mmgl_adamw_step");
     return MMGL_OK;
+}
+
+template <typename T> static int act_launch(const void* x, void* y, size_t n, int act, hipStream_t st) {
+    const int blocks = stream_blocks(n / (16 / sizeof(T)));
+    switch (act) {
+        case 1: hipLaunchKernelGGL((act_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)y, n); break;
+        case 2: hipLaunchKernelGGL((act_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)y, n); break;
+        case 3: hipLaunchKernelGGL((act_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)y, n); break;
+        default: hipLaunchKernelGGL((act_kernel<T, 4>), dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)y, n); break;
+    }
+    MMGL_CHECK_LAUNCH("mmgl_activation_fwd");
+    return MMGL_OK;
+}
+
+extern "C" int mmgl_activation_fwd(const void* x, void* y, size_t n, int act, int dtype, void* stream) {
+    MMGL_CHECK_ARG(x && y, "mmgl_activation_fwd: null pointer");
+    MMGL_CHECK_ARG(act >= 1 && act <= 4, "mmgl_activation_fwd: act %d not in {1 relu, 2 gelu, 3 quick_gelu, 4 gelu_tanh}", act);
+    if (n == 0) return MMGL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMGL_BF16) return act_launch<bf16>(x, y, n, act, st);
+    if (dtype == MMGL_F32) return act_launch<float>(x, y, n, act, st);
+    MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_activation_fwd: bad dtype %d", dtype);
 }

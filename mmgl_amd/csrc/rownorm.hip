@@ -31,8 +31,9 @@ template <int TPR> __device__ __forceinline__ float row_sum(float v, float* red,
 }
 
 template <typename T, int TPR, int NV, bool RMS>
-__global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
-                                                       const T* __restrict__ beta, T* __restrict__ y,
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                       const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                       T* __restrict__ sum_out, T* __restrict__ y,
                                                        float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                        int cols, float eps) {
     typedef typename Vec<T>::type V;
@@ -50,7 +51,13 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
         for (int i = 0; i < NV; ++i) {
             const int c = tr + i * TPR;
             if (live && c < nchunks) {
-                const V v = *(const V*)(x + (size_t)row * cols + c * VN);
+                V v = *(const V*)(x + (size_t)row * cols + c * VN);
+                if (res) {                                    // fused residual add: the sum is rounded to T like torch's x + r
+                    const V r = *(const V*)(res + (size_t)row * cols + c * VN);
+#pragma unroll
+                    for (int j = 0; j < VN; ++j) v[j] = (T)((float)v[j] + (float)r[j]);
+                    if (sum_out) *(V*)(sum_out + (size_t)row * cols + c * VN) = v;
+                }
 #pragma unroll
                 for (int j = 0; j < VN; ++j) { xv[i][j] = (float)v[j]; s += xv[i][j]; }
             } else {
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
         const float rs = rsqrtf(var + eps);
         if (live && tr == 0) {
             if (mean) mean[row] = mu;
-            rstd[row] = rs;
+            if (rstd) rstd[row] = rs;
         }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -239,15 +246,15 @@ int bwd_blocks(int rows, int rpb) {
     } while (0)
 
 template <typename T, bool RMS>
-int norm_fwd(const char* who, const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
-             int rows, int cols, float eps, hipStream_t st) {
+int norm_fwd(const char* who, const void* x, const void* res, const void* gamma, const void* beta, void* sum_out, void* y,
+             float* mean, float* rstd, int rows, int cols, float eps, hipStream_t st) {
     Geo g;
     int rc = geometry<T>(who, rows, cols, g);
     if (rc) return rc;
     int blocks = (rows + g.rpb - 1) / g.rpb;
     if (blocks > 8192) blocks = 8192;
-    NORM_DISPATCH(norm_fwd_kernel, T, RMS, g, dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)gamma,
-                  (const T*)beta, (T*)y, mean, rstd, rows, cols, eps);
+    NORM_DISPATCH(norm_fwd_kernel, T, RMS, g, dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)res, (const T*)gamma,
+                  (const T*)beta, (T*)sum_out, (T*)y, mean, rstd, rows, cols, eps);
     MMGL_CHECK_LAUNCH(who);
     return MMGL_OK;
 }
@@ -291,9 +298,20 @@ extern "C" int mmgl_layernorm_fwd(const void* x, const void* gamma, const void* 
                                   int rows, int cols, float eps, int dtype, void* stream) {
     MMGL_CHECK_ARG(x && y && mean && rstd, "mmgl_layernorm_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MMGL_BF16) return norm_fwd<bf16, false>("mmgl_layernorm_fwd", x, gamma, beta, y, mean, rstd, rows, cols, eps, st);
-    if (dtype == MMGL_F32) return norm_fwd<float, false>("mmgl_layernorm_fwd", x, gamma, beta, y, mean, rstd, rows, cols, eps, st);
+    if (dtype == MMGL_BF16) return norm_fwd<bf16, false>("mmgl_layernorm_fwd", x, nullptr, gamma, beta, nullptr, y, mean, rstd, rows, cols, eps, st);
+    if (dtype == MMGL_F32) return norm_fwd<float, false>("mmgl_layernorm_fwd", x, nullptr, gamma, beta, nullptr, y, mean, rstd, rows, cols, eps, st);
     MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_layernorm_fwd: bad dtype %d", dtype);
+}
+
+extern "C" int mmgl_add_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* sum_out,
+                                      void* y, int rows, int cols, float eps, int dtype, void* stream) {
+    MMGL_CHECK_ARG(x && res && y, "mmgl_add_layernorm_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMGL_BF16)
+        return norm_fwd<bf16, false>("mmgl_add_layernorm_fwd", x, res, gamma, beta, sum_out, y, nullptr, nullptr, rows, cols, eps, st);
+    if (dtype == MMGL_F32)
+        return norm_fwd<float, false>("mmgl_add_layernorm_fwd", x, res, gamma, beta, sum_out, y, nullptr, nullptr, rows, cols, eps, st);
+    MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_add_layernorm_fwd: bad dtype %d", dtype);
 }
 
 extern "C" int mmgl_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
@@ -312,8 +330,8 @@ extern "C" int mmgl_rmsnorm_fwd(const void* x, const void* gamma, void* y, float
                                 int dtype, void* stream) {
     MMGL_CHECK_ARG(x && y && rstd, "mmgl_rmsnorm_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MMGL_BF16) return norm_fwd<bf16, true>("mmgl_rmsnorm_fwd", x, gamma, nullptr, y, nullptr, rstd, rows, cols, eps, st);
-    if (dtype == MMGL_F32) return norm_fwd<float, true>("mmgl_rmsnorm_fwd", x, gamma, nullptr, y, nullptr, rstd, rows, cols, eps, st);
+    if (dtype == MMGL_BF16) return norm_fwd<bf16, true>("mmgl_rmsnorm_fwd", x, nullptr, gamma, nullptr, nullptr, y, nullptr, rstd, rows, cols, eps, st);
+    if (dtype == MMGL_F32) return norm_fwd<float, true>("mmgl_rmsnorm_fwd", x, nullptr, gamma, nullptr, nullptr, y, nullptr, rstd, rows, cols, eps, st);
     MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_rmsnorm_fwd: bad dtype %d", dtype);
 }
 

@@ -41,7 +41,7 @@ template <typename T, typename C, bool K_ROWMAJOR, bool V_ROWMAJOR> struct TileS
             kr[i] = ok ? *(const v8*)(kbase + (size_t)(s0 + s) * row_stride + c * 8) : vzero<v8>();
             vr[i] = ok ? *(const v8*)(vbase + (size_t)(s0 + s) * row_stride + c * 8) : vzero<v8>();
         }
-        vb = (threadIdx.x < KT && s0 + (int)threadIdx.x < T_) ? valid_row[s0 + threadIdx.x] : 0;
+        vb = (threadIdx.x < KT && s0 + (int)threadIdx.x < T_) ? (valid_row ? valid_row[s0 + threadIdx.x] : (uint8_t)1) : 0;
     }
     __device__ __forceinline__ void store(T* Kimg, T* Vimg, uint8_t* vld) const {
 #pragma unroll
@@ -185,6 +185,128 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db) buf_store4<T>(ro, row_off<T, C>(t, row_bytes, db * 16 + g * 4), oacc[qt][db] * inv);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, m[qt] + __logf(lt)), rl, (g == 0) ? (uint32_t)t * 4u : OOB, 0, 0);
+    }
+}
+
+// ============================================================================================ encoder forward (packed, bidirectional)
+// The frozen neighbor encoders (RoBERTa / CLIP ViT; get_text_embs / get_visual_embs, modelling_cross_attention.py:978-1027)
+// run forward-only over PACKED tokens: sequence i owns rows cu[i] .. cu[i+1]-1 of a [ntok, ld] buffer (q, k, v may be three
+// column slices of one fused-QKV GEMM output, ld = 3 H D).  No padding token is ever loaded or multiplied; every key of a
+// sequence is visible to every query (no causal mask), so all key tiles are full work except the ragged last one.
+// `q_rows` limits the query rows computed per sequence (1 = only the CLS row, which is all the last layer has to produce).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void encattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                          const T* __restrict__ v, const int* __restrict__ cu,
+                                                          T* __restrict__ out, int nseq, int H, int ld_in, int ld_out,
+                                                          int nqb, int q_rows) {
+    typedef SC<T, D> C;
+    typedef typename Elem<T>::v8 v8;
+    constexpr int TILE = 16 * C::QT, QB = 4 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Kf = (T*)smem;
+    T* Vi = Kf + C::ROWIMG;
+    uint8_t* vld = (uint8_t*)(Vi + (C::TIMG ? C::RMIMG : C::ROWIMG));
+
+    const int vid = xcd_remap(blockIdx.x, nseq * H * nqb);
+    const int sh = vid / nqb, qblk = vid % nqb;
+    const int seq = sh / H, h = sh % H;
+    const int start = cu[seq], len = cu[seq + 1] - start;
+    const int qlen = min(len, q_rows);
+    if (qblk * QB >= qlen) return;                            // workgroup-uniform: before any barrier
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = lane & 15, g = lane >> 4;
+    const int t0 = qblk * QB + wave * TILE;
+    const int nkt = (len + KT - 1) / KT;
+
+    const uint32_t rb_in = (uint32_t)(ld_in * sizeof(T)), rb_out = (uint32_t)(ld_out * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)start * ld_in + h * D, (uint32_t)(((size_t)(qlen - 1) * ld_in + D) * sizeof(T)));
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)start * ld_out + h * D, (uint32_t)(((size_t)(qlen - 1) * ld_out + D) * sizeof(T)));
+    const T* kb = k + (size_t)start * ld_in + h * D;
+    const T* vb = v + (size_t)start * ld_in + h * D;
+
+    v8 qf[C::QT][C::NDC];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+        for (int dc = 0; dc < C::NDC; ++dc) qf[qt][dc] = buf_load8<T>(rq, row_off<T, C>(t0 + qt * 16 + x, rb_in, dc * 32 + g * 8));
+
+    float m[C::QT], l[C::QT];
+    f32x4 oacc[C::QT][C::NDB];
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        m[qt] = -INFINITY;
+        l[qt] = 0.f;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) oacc[qt][db] = vzero<f32x4>();
+    }
+
+    TileStage<T, C, false, C::TIMG> stg;
+    stg.load(kb, vb, nullptr, (size_t)ld_in, 0, len);
+    stg.store(Kf, Vi, vld);
+    __syncthreads();
+    for (int j = 0; j < nkt; ++j) {
+        if (j + 1 < nkt) stg.load(kb, vb, nullptr, (size_t)ld_in, (j + 1) * KT, len);
+        f32x4 bias[4];
+        tile_bias<C>(vld, g, bias);                           // -inf for the keys past the end of the sequence
+        f32x4 sacc[C::QT][4];
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+            for (int qt = 0; qt < C::QT; ++qt) sacc[qt][sb] = bias[sb];
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc) {
+                const v8 kf = *(const v8*)(Kf + rf_idx<C>(sb, dc, lane));
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt) mma16(sacc[qt][sb], kf, qf[qt][dc]);
+            }
+        }
+        v8 pf[C::QT][2];
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            float tm = fmaxf(fmaxf(sacc[qt][0][0], sacc[qt][0][1]), fmaxf(sacc[qt][0][2], sacc[qt][0][3]));
+#pragma unroll
+            for (int sb = 1; sb < 4; ++sb)
+                tm = fmaxf(tm, fmaxf(fmaxf(sacc[qt][sb][0], sacc[qt][sb][1]), fmaxf(sacc[qt][sb][2], sacc[qt][sb][3])));
+            tm = xg_max(tm);
+            const float mn = fmaxf(m[qt], tm);                // finite from tile 0 on: every tile holds >= 1 real key
+            const float mn2 = mn * LOG2E;
+            const float alpha = __builtin_amdgcn_exp2f(m[qt] * LOG2E - mn2);
+            m[qt] = mn;
+            float ls = 0.f;
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qt][sb][r], LOG2E, -mn2));
+                    sacc[qt][sb][r] = p;
+                    ls += p;
+                }
+            l[qt] = l[qt] * alpha + ls;
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db) oacc[qt][db] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) pf[qt][ks] = pack8<T>(sacc[qt][2 * ks], sacc[qt][2 * ks + 1]);
+        }
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                v8 vt;
+                if constexpr (C::TIMG) vt = rm_tfrag_tr16<C>(Vi, db, ks, lane);
+                else vt = load_tfrag<T, C>(Vi, Vi, db, ks, lane);
+#pragma unroll
+                for (int qt = 0; qt < C::QT; ++qt) mma16(oacc[qt][db], vt, pf[qt][ks]);
+            }
+        __syncthreads();
+        if (j + 1 < nkt) stg.store(Kf, Vi, vld);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        const int t = t0 + qt * 16 + x;
+        const float inv = __builtin_amdgcn_rcpf(xg_sum(l[qt]));
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) buf_store4<T>(ro, row_off<T, C>(t, rb_out, db * 16 + g * 4), oacc[qt][db] * inv);
     }
 }
 
@@ -603,6 +725,22 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
     return MMGL_OK;
 }
 
+template <typename T, int D>
+int enc_fwd(const void* q, const void* k, const void* v, const int* cu, void* out, int nseq, int H, int ld_in, int ld_out,
+            int max_len, int q_rows, hipStream_t st) {
+    typedef SC<T, D> C;
+    const int QB = 4 * 16 * C::QT;
+    const int nqb = cdiv(max_len < q_rows ? max_len : q_rows, QB);
+    const size_t lds = sizeof(T) * (C::ROWIMG + (C::TIMG ? C::RMIMG : C::ROWIMG)) + KT;
+    auto kern = encattn_fwd_kernel<T, D>;
+    int rc = set_lds_sa(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(nseq * H * nqb), dim3(256), lds, st, (const T*)q, (const T*)k, (const T*)v, cu, (T*)out, nseq, H,
+                       ld_in, ld_out, nqb, q_rows);
+    MMGL_CHECK_LAUNCH("encattn_fwd");
+    return MMGL_OK;
+}
+
 int sa_check(const char* who, int B, int H, int T, int D, int dtype) {
     MMGL_CHECK_ARG(B > 0 && H > 0 && T > 0, "%s: B,H,T must be positive (got %d,%d,%d)", who, B, H, T);
     MMGL_CHECK_ARG(dtype == MMGL_F32 || dtype == MMGL_BF16, "%s: dtype must be MMGL_F32 or MMGL_BF16", who);
@@ -646,4 +784,17 @@ extern "C" int mmgl_selfattn_bwd(const void* dout, const void* q, const void* k,
     float* delta = (float*)workspace;
     if (dtype == MMGL_BF16) { SA_DISPATCH(sa_bwd, bf16, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, st) }
     SA_DISPATCH(sa_bwd, float, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, st)
+}
+
+extern "C" int mmgl_encattn_fwd(const void* q, const void* k, const void* v, const int32_t* cu_seqlens, void* out, int nseq,
+                                int H, int D, int ld_in, int ld_out, int max_len, int q_rows, int dtype, void* stream) {
+    int rc = sa_check("mmgl_encattn_fwd", nseq, H, max_len, D, dtype);
+    if (rc) return rc;
+    MMGL_CHECK_ARG(q && k && v && cu_seqlens && out, "mmgl_encattn_fwd: null pointer");
+    MMGL_CHECK_ARG(q_rows > 0, "mmgl_encattn_fwd: q_rows must be positive (got %d)", q_rows);
+    MMGL_CHECK_ARG(ld_in >= H * D && ld_out >= H * D && ld_in % 8 == 0 && ld_out % 8 == 0,
+                   "mmgl_encattn_fwd: row strides (%d, %d) must be >= H*D = %d and multiples of 8 elements", ld_in, ld_out, H * D);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMGL_BF16) { SA_DISPATCH(enc_fwd, bf16, q, k, v, cu_seqlens, out, nseq, H, ld_in, ld_out, max_len, q_rows, st) }
+    SA_DISPATCH(enc_fwd, float, q, k, v, cu_seqlens, out, nseq, H, ld_in, ld_out, max_len, q_rows, st)
 }

@@ -1,0 +1,188 @@
+"""Padding-free forward of the frozen neighbor encoders.
+
+The reference pushes every neighbor through a frozen HF encoder at full padded length and keeps one vector of it
+(`get_text_embs` / `get_visual_embs`, reference model/modelling_cross_attention.py:978-1027: RoBERTa CLS hidden state,
+CLIP-ViT `pooler_output`).  Here the SAME HF modules are loaded through the same `from_pretrained` API and keep their
+parameters / state_dict keys; only their forward is replaced, for CUDA tensors, by a packed pass:
+
+  * valid tokens of all neighbor sequences are concatenated ([ntok, hidden], `cu_seqlens`); no pad token is embedded,
+    multiplied or attended to (dropping masked keys leaves every softmax unchanged: their weight is exactly 0);
+  * per layer: one fused-QKV GEMM (library GEMM, the D^-1/2 scaling folded into the Q rows), `mmgl_encattn_fwd`
+    (hand-written flash-style HIP kernel reading Q/K/V straight out of the fused buffer), output GEMM,
+    `mmgl_add_layernorm_fwd` (residual add + LayerNorm in one pass), FFN GEMMs with `mmgl_activation_fwd` in place;
+  * the last layer only produces what is consumed: keys/values for all tokens, but attention output, output projection,
+    FFN and norms for the first (CLS) row of every sequence only.
+
+Forward only, no autograd (the encoders are frozen, reference :922-934).  Anything this path does not cover (CPU tensors,
+other architectures, relative position embeddings, a sequence whose first token is masked) returns None and the caller
+uses the HF module itself.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+
+_HEAD_DIMS = (16, 32, 64, 128)
+
+
+def _key(*params):
+    return tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
+
+
+class _Fused:
+    """Per-layer fused QKV weight/bias (Q rows pre-scaled), rebuilt when the source parameters change."""
+
+    def __init__(self):
+        self.key = None
+        self.layers = None
+
+    def get(self, triples, scale):
+        key = _key(*[t[0].weight for t in triples], *[t[2].weight for t in triples])
+        if key != self.key:
+            layers = []
+            for q, k, v in triples:
+                w = torch.cat([q.weight.detach().float() * scale, k.weight.detach().float(), v.weight.detach().float()], 0).to(q.weight.dtype)
+                b = torch.cat([q.bias.detach().float() * scale, k.bias.detach().float(), v.bias.detach().float()], 0).to(q.weight.dtype)
+                layers.append((w.contiguous(), b.contiguous()))
+            self.key, self.layers = key, layers
+        return self.layers
+
+
+def _cu_from_lens(lens):
+    cu = torch.zeros(lens.numel() + 1, dtype=torch.int32, device=lens.device)
+    cu[1:] = torch.cumsum(lens, 0)
+    return cu
+
+
+class PackedTextEncoder:
+    """RoBERTa/BERT-style post-LN encoder (`RobertaModel`): CLS hidden state of the last layer for [n, L] id / mask rows."""
+
+    def __init__(self, model):
+        self.model = model
+        self._fused = _Fused()
+        self._pos_type = (None, None)
+
+    @staticmethod
+    def supports(model):
+        cfg = getattr(model, "config", None)
+        emb = getattr(model, "embeddings", None)
+        enc = getattr(model, "encoder", None)
+        if cfg is None or emb is None or enc is None or not hasattr(enc, "layer"):
+            return False
+        if not all(hasattr(emb, a) for a in ("word_embeddings", "position_embeddings", "token_type_embeddings", "LayerNorm")):
+            return False
+        if getattr(cfg, "position_embedding_type", None) not in (None, "absolute") or getattr(cfg, "is_decoder", False):
+            return False
+        if not isinstance(cfg.hidden_act, str) or cfg.hidden_act not in ops.ACT_CODES:
+            return False
+        D = cfg.hidden_size // cfg.num_attention_heads
+        return D in _HEAD_DIMS and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0
+
+    def _pos_type_table(self):
+        emb = self.model.embeddings
+        key = _key(emb.position_embeddings.weight, emb.token_type_embeddings.weight)
+        if self._pos_type[0] != key:        # token_type_ids default to 0 everywhere (HF buffer of zeros)
+            w = emb.position_embeddings.weight
+            self._pos_type = (key, (w.detach().float() + emb.token_type_embeddings.weight.detach()[0].float()).to(w.dtype))
+        return self._pos_type[1]
+
+    @torch.no_grad()
+    def cls(self, ids, am):
+        m = self.model
+        cfg = m.config
+        if not ids.is_cuda or ids.shape[0] == 0:
+            return None
+        n, L = ids.shape
+        amb = am != 0
+        lens = amb.sum(1)
+        host = torch.stack([lens, amb[:, 0].to(lens.dtype)]).cpu()          # the one host sync of the text pass
+        if not bool(host[1].all()):
+            return None                      # a sequence without its first token: CLS row would not be row 0 of the pack
+        total, max_len = int(host[0].sum()), int(host[0].max())
+        cu = _cu_from_lens(lens)
+        flat = amb.reshape(-1)
+        tok = torch.nonzero_static(flat, size=total).squeeze(1) if hasattr(torch, "nonzero_static") else flat.nonzero().squeeze(1)
+
+        emb = m.embeddings
+        pad = emb.padding_idx if getattr(emb, "padding_idx", None) is not None else cfg.pad_token_id
+        ne = ids.ne(pad)
+        pos = (torch.cumsum(ne, 1) * ne + pad).reshape(-1)                   # create_position_ids_from_input_ids
+        x = emb.word_embeddings.weight.index_select(0, ids.reshape(-1).index_select(0, tok))
+        pe = self._pos_type_table().index_select(0, pos.index_select(0, tok))
+        h = ops.add_layer_norm(x, pe, emb.LayerNorm.weight, emb.LayerNorm.bias, cfg.layer_norm_eps)
+
+        H = cfg.num_attention_heads
+        hid = cfg.hidden_size
+        layers = list(m.encoder.layer)
+        fused = self._fused.get([(l.attention.self.query, l.attention.self.key, l.attention.self.value) for l in layers],
+                                1.0 / math.sqrt(hid // H))
+        first_rows = cu[:-1].long()
+        for li, layer in enumerate(layers):
+            last = li == len(layers) - 1
+            qkv = F.linear(h, *fused[li])
+            ctx = ops.encoder_attention(qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:], cu, H, max_len, q_rows=1 if last else None)
+            if last:                         # only the CLS rows are consumed downstream
+                ctx, h = ctx.index_select(0, first_rows), h.index_select(0, first_rows)
+            ao = layer.attention.output
+            h1 = ops.add_layer_norm(F.linear(ctx, ao.dense.weight, ao.dense.bias), h, ao.LayerNorm.weight, ao.LayerNorm.bias, cfg.layer_norm_eps)
+            f = ops.activation_(F.linear(h1, layer.intermediate.dense.weight, layer.intermediate.dense.bias), cfg.hidden_act)
+            lo = layer.output
+            h = ops.add_layer_norm(F.linear(f, lo.dense.weight, lo.dense.bias), h1, lo.LayerNorm.weight, lo.LayerNorm.bias, cfg.layer_norm_eps)
+        return h                             # [n, hidden]
+
+
+class PackedVisionEncoder:
+    """CLIP ViT (pre-LN) encoder: `pooler_output` = post_layernorm(CLS of the last layer) for [n, 3, H, W] pixels."""
+
+    def __init__(self, model):
+        self.model = model
+        self._fused = _Fused()
+
+    @staticmethod
+    def _core(model):
+        return getattr(model, "vision_model", model)
+
+    @staticmethod
+    def supports(model):
+        core = PackedVisionEncoder._core(model)
+        cfg = getattr(model, "config", None)
+        if cfg is None or not all(hasattr(core, a) for a in ("embeddings", "pre_layrnorm", "encoder", "post_layernorm")):
+            return False
+        if not hasattr(core.encoder, "layers") or not isinstance(cfg.hidden_act, str) or cfg.hidden_act not in ops.ACT_CODES:
+            return False
+        D = cfg.hidden_size // cfg.num_attention_heads
+        return D in _HEAD_DIMS and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0
+
+    @torch.no_grad()
+    def pooled(self, pixel_values):
+        core = self._core(self.model)
+        cfg = self.model.config
+        if not pixel_values.is_cuda or pixel_values.shape[0] == 0:
+            return None
+        e = core.embeddings(pixel_values)                                   # patch GEMM + class token + positions: [n, S, hid]
+        n, S, hid = e.shape
+        H = cfg.num_attention_heads
+        eps = cfg.layer_norm_eps
+        x = ops.layer_norm(e.reshape(n * S, hid), core.pre_layrnorm.weight, core.pre_layrnorm.bias, eps)
+        cu = torch.arange(0, (n + 1) * S, S, dtype=torch.int32, device=x.device)
+        layers = list(core.encoder.layers)
+        fused = self._fused.get([(l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj) for l in layers], 1.0 / math.sqrt(hid // H))
+        first_rows = cu[:-1].long()
+        y = ops.layer_norm(x, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, eps) if layers else None
+        for li, layer in enumerate(layers):
+            last = li == len(layers) - 1
+            qkv = F.linear(y, *fused[li])
+            ctx = ops.encoder_attention(qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:], cu, H, S, q_rows=1 if last else None)
+            if last:
+                ctx, x = ctx.index_select(0, first_rows), x.index_select(0, first_rows)
+            a = F.linear(ctx, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias)
+            x, y2 = ops.add_layer_norm(a, x, layer.layer_norm2.weight, layer.layer_norm2.bias, eps, return_sum=True)
+            f = ops.activation_(F.linear(y2, layer.mlp.fc1.weight, layer.mlp.fc1.bias), cfg.hidden_act)
+            f2 = F.linear(f, layer.mlp.fc2.weight, layer.mlp.fc2.bias)
+            if last:
+                return ops.add_layer_norm(f2, x, core.post_layernorm.weight, core.post_layernorm.bias, eps)
+            nxt = layers[li + 1].layer_norm1
+            x, y = ops.add_layer_norm(f2, x, nxt.weight, nxt.bias, eps, return_sum=True)
+        return ops.layer_norm(x.index_select(0, first_rows), core.post_layernorm.weight, core.post_layernorm.bias, eps)

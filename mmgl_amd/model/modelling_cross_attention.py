@@ -30,6 +30,7 @@ from transformers.activations import ACT2FN
 from transformers.modeling_outputs import BaseModelOutputWithPast, CausalLMOutputWithPast
 
 from .. import ops
+from .encoders import PackedTextEncoder, PackedVisionEncoder
 
 CROSS_MODES = ("cross_attention", "embedding")
 
@@ -654,6 +655,10 @@ class CrossAttentionModel(nn.Module):
         # the frozen encoders skip them (the reference encodes '' texts and all-zero images, data.py:444-454).
         self.skip_padded_neighbors = getattr(args, "skip_padded_neighbors", True)
         self.text_length_buckets = getattr(args, "text_length_buckets", 4)     # 1 = encode everything padded to L (reference)
+        # packed (padding-free) HIP forward of the frozen encoders; the HF modules stay the owners of the weights
+        self.packed_encoders = getattr(args, "packed_encoders", True)
+        self._packed_text = PackedTextEncoder(self.text_model) if (self.text_model is not None and PackedTextEncoder.supports(self.text_model)) else None
+        self._packed_visual = PackedVisionEncoder(self.visual_model) if (self.visual_model is not None and PackedVisionEncoder.supports(self.visual_model)) else None
 
         if self.args.freeze_lm:
             print("Freezing the LM.")
@@ -709,7 +714,9 @@ class CrossAttentionModel(nn.Module):
             if rows is not None:
                 ids, am = ids.index_select(0, rows), am.index_select(0, rows)
             is_clip = "clip" in self.args.text_model
-            enc = encode_text_bucketed(self.text_model, ids, am, 1 if is_clip else self.text_length_buckets, use_pooler_output=is_clip)
+            enc = self._packed_text.cls(ids, am) if (self.packed_encoders and self._packed_text is not None and not is_clip) else None
+            if enc is None:
+                enc = encode_text_bucketed(self.text_model, ids, am, 1 if is_clip else self.text_length_buckets, use_pooler_output=is_clip)
             if rows is not None:
                 full = enc.new_zeros(batch_size * neighbor_num, enc.shape[-1])
                 enc = full.index_copy_(0, rows, enc)
@@ -731,7 +738,10 @@ class CrossAttentionModel(nn.Module):
             if pv.shape[0] == 0:
                 pooled = pixel_values.new_zeros(0, hidden, dtype=next(self.visual_model.parameters()).dtype)
             else:
-                pooled = self.visual_model(pv.to(next(self.visual_model.parameters()).dtype)).pooler_output
+                pv = pv.to(next(self.visual_model.parameters()).dtype)
+                pooled = self._packed_visual.pooled(pv) if (self.packed_encoders and self._packed_visual is not None) else None
+                if pooled is None:
+                    pooled = self.visual_model(pv).pooler_output
             if rows is not None:
                 pooled = pooled.new_zeros(batch_size * neighbor_num, hidden).index_copy_(0, rows, pooled)
         return self._project(pooled, self.visual_embeddings, self.visual_position_embeddings, pos_ids, batch_size, self.n_visual_tokens)

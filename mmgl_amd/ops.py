@@ -424,3 +424,57 @@ def adamw_step_(param, master, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
     require_cuda(param, grad)
     _lib.call("mmgl_adamw_step", None, ptr(param), ptr(master), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, beta1, beta2,
                                 eps, weight_decay, step, grad_scale, dtype_code(param), stream_ptr())
+
+
+# ------------------------------------------------------------------------------------------ frozen encoders (forward only)
+ACT_CODES = {"relu": 1, "gelu": 2, "quick_gelu": 3, "gelu_new": 4, "gelu_pytorch_tanh": 4, "gelu_fast": 4}
+
+
+def encoder_attention(q, k, v, cu_seqlens, num_heads, max_len, q_rows=None):
+    """Bidirectional attention over packed sequences (no padding rows exist).  q, k, v: [ntok, H*D] views with a common
+    row stride (e.g. the three column slices of a fused-QKV output); q pre-scaled by D^-1/2; cu_seqlens int32 [nseq+1].
+    Returns [ntok, H*D]; with q_rows < max_len only the first q_rows rows of every sequence are written.
+    No autograd: the encoders are frozen (reference modelling_cross_attention.py:922-934)."""
+    require_cuda(q, k, v, cu_seqlens)
+    ntok, hd = q.shape
+    if k.shape != q.shape or v.shape != q.shape or hd % num_heads:
+        raise ValueError(f"encoder_attention: incompatible shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)} H={num_heads}")
+    ld = q.stride(0)
+    if q.stride(1) != 1 or k.stride() != q.stride() or v.stride() != q.stride():
+        raise ValueError("encoder_attention: q, k, v need unit column stride and one common row stride")
+    if cu_seqlens.dtype != torch.int32:
+        raise ValueError("encoder_attention: cu_seqlens must be int32")
+    out = torch.empty(ntok, hd, dtype=q.dtype, device=q.device)
+    nseq = cu_seqlens.numel() - 1
+    if nseq <= 0 or ntok == 0:
+        return out
+    _lib.call("mmgl_encattn_fwd", None, ptr(q), ptr(k), ptr(v), ptr(cu_seqlens), ptr(out), nseq, num_heads, hd // num_heads, ld, hd,
+              int(max_len), int(max_len if q_rows is None else q_rows), dtype_code(q), stream_ptr())
+    return out
+
+
+def add_layer_norm(x, res, gamma, beta, eps, return_sum=False):
+    """y = LayerNorm(x + res) in one pass (optionally also returning the sum = the new residual stream).  Forward only."""
+    require_cuda(x, res)
+    if x.shape != res.shape:
+        raise ValueError(f"add_layer_norm: shapes differ {tuple(x.shape)} vs {tuple(res.shape)}")
+    cols = x.shape[-1]
+    x2, r2 = x.contiguous().view(-1, cols), res.contiguous().view(-1, cols)
+    y = torch.empty_like(x2)
+    s = torch.empty_like(x2) if return_sum else None
+    g, b = gamma.to(x.dtype).contiguous(), beta.to(x.dtype).contiguous()
+    if x2.shape[0]:
+        _lib.call("mmgl_add_layernorm_fwd", None, ptr(x2), ptr(r2), ptr(g), ptr(b), ptr(s), ptr(y), x2.shape[0], cols, float(eps),
+                  dtype_code(x2), stream_ptr())
+    return (s.view(x.shape), y.view(x.shape)) if return_sum else y.view(x.shape)
+
+
+def activation_(x, name):
+    """In-place HF ACT2FN[name] over a contiguous tensor (one pass).  Forward only."""
+    require_cuda(x)
+    if name not in ACT_CODES:
+        raise ValueError(f"activation_: unsupported activation {name!r}")
+    if not x.is_contiguous():
+        raise ValueError("activation_: tensor must be contiguous")
+    _lib.call("mmgl_activation_fwd", None, ptr(x), ptr(x), x.numel(), ACT_CODES[name], dtype_code(x), stream_ptr())
+    return x

@@ -1,0 +1,151 @@
+"""Packed (padding-free) frozen-encoder forward vs the HF modules it replaces, and its three kernels vs torch fp32.
+
+The HF modules here are the very objects the reference calls (`self.text_model(...)`, `self.visual_model(...)`,
+reference model/modelling_cross_attention.py:992, 1018); random-init, no checkpoint needed.  Tolerances: fp32 2e-4
+relative to the output scale (different summation order + online softmax), bf16 4e-2.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-6)).item()
+
+
+def _ragged_lens(n, L, gen):
+    lens = torch.randint(1, L + 1, (n,), generator=gen)
+    lens[0] = L
+    if n > 1:
+        lens[1] = 1
+    return lens
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("H,D", [(4, 16), (2, 32), (12, 64), (2, 128)])
+def test_encoder_attention_vs_torch(dtype, tol, H, D):
+    from mmgl_amd import ops
+    gen = torch.Generator().manual_seed(H * 100 + D)
+    n, L = 7, 150
+    lens = _ragged_lens(n, L, gen)
+    cu = torch.zeros(n + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    ntok = int(cu[-1])
+    qkv = torch.randn(ntok, 3 * H * D, generator=gen).to(dtype).cuda()
+    hd = H * D
+    q, k, v = qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:]
+    scale = 1.0 / math.sqrt(D)
+    qs = (qkv.float() * 1).clone()
+    qs[:, :hd] *= scale
+    qs = qs.to(dtype)
+    out = ops.encoder_attention(qs[:, :hd], qs[:, hd:2 * hd], qs[:, 2 * hd:], cu.cuda(), H, int(lens.max()))
+    out1 = ops.encoder_attention(qs[:, :hd], qs[:, hd:2 * hd], qs[:, 2 * hd:], cu.cuda(), H, int(lens.max()), q_rows=1)
+    for i in range(n):
+        a, b = int(cu[i]), int(cu[i + 1])
+        qi = qs[a:b, :hd].float().view(b - a, H, D).transpose(0, 1)
+        ki = k[a:b].float().view(b - a, H, D).transpose(0, 1)
+        vi = v[a:b].float().view(b - a, H, D).transpose(0, 1)
+        ref = torch.softmax(qi @ ki.transpose(1, 2), -1) @ vi
+        ref = ref.transpose(0, 1).reshape(b - a, hd)
+        assert _rel(out[a:b], ref) < tol, (i, b - a)
+        assert _rel(out1[a:a + 1], ref[:1]) < tol, (i, b - a)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("cols", [64, 768, 1024, 4096])
+def test_add_layer_norm(dtype, tol, cols):
+    from mmgl_amd import ops
+    torch.manual_seed(cols)
+    x, r = torch.randn(37, cols).to(dtype).cuda(), torch.randn(37, cols).to(dtype).cuda()
+    g, b = torch.randn(cols).to(dtype).cuda(), torch.randn(cols).to(dtype).cuda()
+    s, y = ops.add_layer_norm(x, r, g, b, 1e-5, return_sum=True)
+    s_ref = x + r
+    assert torch.equal(s, s_ref)
+    y_ref = torch.nn.functional.layer_norm(s_ref.float(), (cols,), g.float(), b.float(), 1e-5)
+    assert _rel(y, y_ref) < tol
+    assert _rel(ops.add_layer_norm(x, r, g, b, 1e-5), y_ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("name", ["relu", "gelu", "quick_gelu", "gelu_new"])
+def test_activation(dtype, tol, name):
+    from transformers.activations import ACT2FN
+    from mmgl_amd import ops
+    torch.manual_seed(0)
+    x = (torch.randn(33, 1001) * 3).to(dtype).cuda()
+    ref = ACT2FN[name](x.float())
+    y = ops.activation_(x.clone(), name)
+    assert _rel(y, ref) < tol
+
+
+def _text_model(hidden, heads, layers, inter, vocab=120, L=48):
+    from transformers import RobertaConfig, RobertaModel
+    cfg = RobertaConfig(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                        intermediate_size=inter, max_position_embeddings=L + 2, hidden_dropout_prob=0.1,
+                        attention_probs_dropout_prob=0.1)
+    torch.manual_seed(7)
+    return RobertaModel(cfg).eval()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("hidden,heads,layers,inter", [(64, 4, 3, 128), (768, 12, 2, 3072)])
+def test_packed_text_encoder_matches_hf(dtype, tol, hidden, heads, layers, inter):
+    from mmgl_amd.model.encoders import PackedTextEncoder
+    L = 48
+    model = _text_model(hidden, heads, layers, inter, L=L).to(dtype).cuda()
+    assert PackedTextEncoder.supports(model)
+    gen = torch.Generator().manual_seed(3)
+    n = 9
+    lens = _ragged_lens(n, L, gen)
+    ids = torch.randint(3, 120, (n, L), generator=gen)
+    am = (torch.arange(L)[None] < lens[:, None]).long()
+    ids = torch.where(am.bool(), ids, torch.ones_like(ids))          # pad id 1 where masked
+    ids[:, 0] = 0
+    ids, am = ids.cuda(), am.cuda()
+    with torch.no_grad():
+        ref = model(input_ids=ids, attention_mask=am).last_hidden_state[:, 0]
+    got = PackedTextEncoder(model).cls(ids, am)
+    assert got is not None and got.shape == ref.shape
+    assert _rel(got, ref) < tol
+    # a sequence whose first token is masked is not packable: the caller must fall back to the HF module
+    am2 = am.clone()
+    am2[2, 0] = 0
+    assert PackedTextEncoder(model).cls(ids, am2) is None
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("hidden,heads,layers,inter,img,patch", [(64, 4, 3, 128, 32, 8), (768, 12, 2, 3072, 224, 16)])
+def test_packed_vision_encoder_matches_hf(dtype, tol, hidden, heads, layers, inter, img, patch):
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from mmgl_amd.model.encoders import PackedVisionEncoder
+    cfg = CLIPVisionConfig(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=heads,
+                           image_size=img, patch_size=patch)
+    torch.manual_seed(11)
+    model = CLIPVisionModel(cfg).eval().to(dtype).cuda()
+    assert PackedVisionEncoder.supports(model)
+    pv = torch.randn(5, 3, img, img, generator=torch.Generator().manual_seed(5)).to(dtype).cuda()
+    with torch.no_grad():
+        ref = model(pv).pooler_output
+    got = PackedVisionEncoder(model).pooled(pv)
+    assert got is not None and got.shape == ref.shape
+    assert _rel(got, ref) < tol
+
+
+def test_fused_weights_follow_parameter_updates():
+    from mmgl_amd.model.encoders import PackedTextEncoder
+    model = _text_model(64, 4, 2, 128).cuda()
+    enc = PackedTextEncoder(model)
+    ids = torch.randint(3, 120, (4, 48)).cuda()
+    ids[:, 0] = 0
+    am = torch.ones_like(ids)
+    a = enc.cls(ids, am)
+    with torch.no_grad():
+        model.encoder.layer[0].attention.self.query.weight.normal_(0, 1.0)
+        model.embeddings.position_embeddings.weight.normal_(0, 0.5)
+    b = enc.cls(ids, am)
+    with torch.no_grad():
+        ref = model(input_ids=ids, attention_mask=am).last_hidden_state[:, 0]
+    assert _rel(b, ref) < 2e-4 and _rel(a, ref) > 1e-3
