@@ -78,13 +78,16 @@ int mmgl_xattn_bwd(const void* dout, const void* q, const void* k, const void* v
  * keeps at least one key and the result equals the reference's finfo.min-clamped softmax; the host wrapper checks it.
  * SURVEY.md 8(f) row 2.  Backward returns dq, dk, dv (the layers are frozen, activations still need gradients);
  * `out` is the forward output (delta = rowsum(dO*O)); workspace >= mmgl_selfattn_bwd_workspace bytes.
+ * ld_qkv / ld_dqkv: row stride in elements of q,k,v / dq,dk,dv; 0 = packed (H*D).  With 3*H*D the three pointers are
+ * column slices of ONE fused projection output / gradient buffer (one fused-QKV GEMM forward, one dgrad GEMM backward).
+ * out, dout are always packed.
  */
 int mmgl_selfattn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out, float* lse,
-                      int B, int H, int T, int D, int dtype, void* stream);
+                      int B, int H, int T, int D, int ld_qkv, int dtype, void* stream);
 size_t mmgl_selfattn_bwd_workspace(int B, int H, int T);
 int mmgl_selfattn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse,
                       const uint8_t* key_valid, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
-                      int B, int H, int T, int D, int dtype, void* stream);
+                      int B, int H, int T, int D, int ld_qkv, int ld_dqkv, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (affine, eps inside the sqrt) over the last dim.

@@ -26,9 +26,9 @@ SIGNATURES = {
     "mmgl_xattn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, U, U, I, P]),
     "mmgl_xattn_bwd_workspace": (Z, [I, I, I, I, I]),
     "mmgl_xattn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, P]),
-    "mmgl_selfattn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "mmgl_selfattn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "mmgl_selfattn_bwd_workspace": (Z, [I, I, I]),
-    "mmgl_selfattn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
+    "mmgl_selfattn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, I, P]),
     "mmgl_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, I, P]),
     "mmgl_norm_bwd_workspace": (Z, [I, I]),
     "mmgl_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, I, P]),
@@ -98,6 +98,11 @@ def dtype_code(t: torch.Tensor) -> int:
 
 def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_off(t, nbytes):
+    """Device pointer `nbytes` past the start of t (a column slice of a fused buffer)."""
+    return ctypes.c_void_p(t.data_ptr() + int(nbytes))
 
 
 def stream_ptr():

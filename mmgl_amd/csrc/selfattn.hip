@@ -61,7 +61,7 @@ template <typename T, int D>
 __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                            const T* __restrict__ v, const uint8_t* __restrict__ valid,
                                                            T* __restrict__ out, float* __restrict__ lse, int B, int H,
-                                                           int T_, int nqb) {
+                                                           int T_, int nqb, int ldq) {
     typedef SC<T, D> C;
     typedef typename Elem<T>::v8 v8;
     constexpr int TILE = 16 * C::QT, QB = 4 * TILE;
@@ -79,19 +79,20 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
     const int t0 = qblk * QB + wave * TILE;
     const int nkt = (min(T_, (qblk + 1) * QB) + KT - 1) / KT;
 
-    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    // q, k, v rows are ldq elements apart (ldq = 3 H D when they are column slices of one fused-QKV GEMM output)
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T)), rbq = (uint32_t)(ldq * sizeof(T));
     const uint32_t slab = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * ldq + h * D, (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T)));
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)b * T_ * HD + h * D, slab);
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
-    const T* kb = k + (size_t)b * T_ * HD + h * D;
-    const T* vb = v + (size_t)b * T_ * HD + h * D;
+    const T* kb = k + (size_t)b * T_ * ldq + h * D;
+    const T* vb = v + (size_t)b * T_ * ldq + h * D;
 
     v8 qf[C::QT][C::NDC];
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt)
 #pragma unroll
-        for (int dc = 0; dc < C::NDC; ++dc) qf[qt][dc] = buf_load8<T>(rq, row_off<T, C>(t0 + qt * 16 + x, row_bytes, dc * 32 + g * 8));
+        for (int dc = 0; dc < C::NDC; ++dc) qf[qt][dc] = buf_load8<T>(rq, row_off<T, C>(t0 + qt * 16 + x, rbq, dc * 32 + g * 8));
 
     float m[C::QT], l[C::QT];
     f32x4 oacc[C::QT][C::NDB];
@@ -104,12 +105,12 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
     }
 
     TileStage<T, C, false, C::TIMG> stg;
-    stg.load(kb, vb, valid + (size_t)b * T_, HD, 0, T_);
+    stg.load(kb, vb, valid + (size_t)b * T_, (size_t)ldq, 0, T_);
     stg.store(Kf, Vi, vld);
     __syncthreads();
     for (int j = 0; j < nkt; ++j) {
         const int s0 = j * KT;
-        if (j + 1 < nkt) stg.load(kb, vb, valid + (size_t)b * T_, HD, s0 + KT, T_);
+        if (j + 1 < nkt) stg.load(kb, vb, valid + (size_t)b * T_, (size_t)ldq, s0 + KT, T_);
         if (s0 <= t0 + TILE - 1) {                            // else: tile entirely above this wave's diagonal (wave-uniform)
 
         f32x4 bias[4];
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
                                                               const T* __restrict__ k, const T* __restrict__ v,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               const uint8_t* __restrict__ valid, T* __restrict__ dq, int B, int H,
-                                                              int T_, int nqb) {
+                                                              int T_, int nqb, int ldq, int ldg) {
     typedef XC<T, D, 4, 2> C;
     typedef typename Elem<T>::v8 v8;
     constexpr int TILE = 16 * C::QT, QB = 4 * TILE;
@@ -361,13 +362,13 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
     const int t0 = qblk * QB + wave * TILE;
     const int nkt = (min(T_, (qblk + 1) * QB) + KT - 1) / KT;
 
-    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T)), rbq = (uint32_t)(ldq * sizeof(T)), rbg = (uint32_t)(ldg * sizeof(T));
     const uint32_t slab = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * ldq + h * D, (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T)));
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(dout + (size_t)b * T_ * HD + h * D, slab);
-    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dq + (size_t)b * T_ * HD + h * D, slab);
-    const T* kb = k + (size_t)b * T_ * HD + h * D;
-    const T* vb = v + (size_t)b * T_ * HD + h * D;
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dq + (size_t)b * T_ * ldg + h * D, (uint32_t)(((size_t)(T_ - 1) * ldg + D) * sizeof(T)));
+    const T* kb = k + (size_t)b * T_ * ldq + h * D;
+    const T* vb = v + (size_t)b * T_ * ldq + h * D;
 
     v8 qf[C::QT][C::NDC], gf[C::QT][C::NDC];
     float lse2[C::QT], dlt[C::QT];
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
         dlt[qt] = (t < T_) ? delta[(size_t)bh * T_ + t] : 0.f;
 #pragma unroll
         for (int dc = 0; dc < C::NDC; ++dc) {
-            qf[qt][dc] = buf_load8<T>(rq, row_off<T, C>(t, row_bytes, dc * 32 + g * 8));
+            qf[qt][dc] = buf_load8<T>(rq, row_off<T, C>(t, rbq, dc * 32 + g * 8));
             gf[qt][dc] = buf_load8<T>(rg, row_off<T, C>(t, row_bytes, dc * 32 + g * 8));
         }
     }
@@ -389,12 +390,12 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
         for (int db = 0; db < C::NDB; ++db) acc[qt][db] = vzero<f32x4>();
 
     TileStage<T, C, C::TIMG, false> stg;
-    stg.load(kb, vb, valid + (size_t)b * T_, HD, 0, T_);
+    stg.load(kb, vb, valid + (size_t)b * T_, (size_t)ldq, 0, T_);
     stg.store(Ki, Vf, vld);
     __syncthreads();
     for (int j = 0; j < nkt; ++j) {
         const int s0 = j * KT;
-        if (j + 1 < nkt) stg.load(kb, vb, valid + (size_t)b * T_, HD, s0 + KT, T_);
+        if (j + 1 < nkt) stg.load(kb, vb, valid + (size_t)b * T_, (size_t)ldq, s0 + KT, T_);
         if (s0 <= t0 + TILE - 1) {
 
         f32x4 bias[4];
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
     for (int qt = 0; qt < C::QT; ++qt) {
         const int t = t0 + qt * 16 + x;
 #pragma unroll
-        for (int db = 0; db < C::NDB; ++db) buf_store4<T>(rd, row_off<T, C>(t, row_bytes, db * 16 + g * 4), acc[qt][db]);
+        for (int db = 0; db < C::NDB; ++db) buf_store4<T>(rd, row_off<T, C>(t, rbg, db * 16 + g * 4), acc[qt][db]);
     }
 }
 
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
                                                                const T* __restrict__ k, const T* __restrict__ v,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                const uint8_t* __restrict__ valid, T* __restrict__ dk,
-                                                               T* __restrict__ dv, int B, int H, int T_, int nkb) {
+                                                               T* __restrict__ dv, int B, int H, int T_, int nkb, int ldq, int ldg) {
     typedef XC<T, D, 2> C;                         // one wave's key group: 32 keys = 2 blocks
     typedef typename Elem<T>::v8 v8;
     constexpr int LDT = C::DPAD + 16;              // row stride of the wave-private tiles (elements)
@@ -488,13 +489,13 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
     const int b = bh / H, h = bh % H;
     const size_t HD = (size_t)H * D;
     const int s0 = kblk * KT + half * 32;
-    const T* kb = k + ((size_t)b * T_ + kblk * KT) * HD + h * D;
-    const T* vb = v + ((size_t)b * T_ + kblk * KT) * HD + h * D;
+    const T* kb = k + ((size_t)b * T_ + kblk * KT) * ldq + h * D;
+    const T* vb = v + ((size_t)b * T_ + kblk * KT) * ldq + h * D;
 
     // stage both halves' K / V row fragments (64 keys): image `half` holds keys [32 half, 32 half + 32)
     for (int hh = 0; hh < 2; ++hh) {
-        stage_row_image<T, C>(Kb + hh * C::ROWIMG, kb + (size_t)hh * 32 * HD, HD, T_ - (kblk * KT + hh * 32));
-        stage_row_image<T, C>(Vb + hh * C::ROWIMG, vb + (size_t)hh * 32 * HD, HD, T_ - (kblk * KT + hh * 32));
+        stage_row_image<T, C>(Kb + hh * C::ROWIMG, kb + (size_t)hh * 32 * ldq, (size_t)ldq, T_ - (kblk * KT + hh * 32));
+        stage_row_image<T, C>(Vb + hh * C::ROWIMG, vb + (size_t)hh * 32 * ldq, (size_t)ldq, T_ - (kblk * KT + hh * 32));
     }
     bool vs[2];
 #pragma unroll
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
 #pragma unroll
         for (int sbl = 0; sbl < 2; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
 
-    const T* qb = q + (size_t)b * T_ * HD + h * D;
+    const T* qb = q + (size_t)b * T_ * ldq + h * D;
     const T* gb = dout + (size_t)b * T_ * HD + h * D;
     const float* lb = lse + (size_t)bh * T_;
     const float* dlb = delta + (size_t)bh * T_;
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
 #pragma unroll
         for (int dc = 0; dc < C::NDC; ++dc) {
             const int t = tfirst + par * 32 + tb * 16 + x;
-            qn[tb][dc] = load_qfrag<T, C>(qb, t, T_, HD, dc * 32 + g * 8);
+            qn[tb][dc] = load_qfrag<T, C>(qb, t, T_, (size_t)ldq, dc * 32 + g * 8);
             gn[tb][dc] = load_qfrag<T, C>(gb, t, T_, HD, dc * 32 + g * 8);
         }
     for (int t0 = tfirst + par * 32; t0 < T_; t0 += 32 * PAR) {
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
                 qa[tb][dc] = qn[tb][dc];
                 ga[tb][dc] = gn[tb][dc];
                 const int tn = t0 + 32 * PAR + tb * 16 + x;
-                qn[tb][dc] = load_qfrag<T, C>(qb, tn, T_, HD, dc * 32 + g * 8);
+                qn[tb][dc] = load_qfrag<T, C>(qb, tn, T_, (size_t)ldq, dc * 32 + g * 8);
                 gn[tb][dc] = load_qfrag<T, C>(gb, tn, T_, HD, dc * 32 + g * 8);
                 *(v8*)(Qt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = qa[tb][dc];
                 *(v8*)(Gt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = ga[tb][dc];
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
         for (int sbl = 0; sbl < 2; ++sbl) {
             const int s = s0 + sbl * 16 + x;
             if (s < T_) {
-                const size_t off = ((size_t)b * T_ + s) * HD + h * D + g * 4;
+                const size_t off = ((size_t)b * T_ + s) * ldg + h * D + g * 4;
 #pragma unroll
                 for (int db = 0; db < C::NDB; ++db) {
                     f32x4 a = dka[db][sbl], c = dva[db][sbl];
@@ -663,7 +664,7 @@ template <typename K> int set_lds_sa(K kern, size_t bytes) {
 
 template <typename T, int D>
 int sa_fwd(const void* q, const void* k, const void* v, const uint8_t* valid, void* out, float* lse, int B, int H, int T_,
-           hipStream_t st) {
+           int ldq, hipStream_t st) {
     typedef SC<T, D> C;
     const int QB = 4 * 16 * C::QT, nqb = cdiv(T_, QB);
     const size_t lds = sizeof(T) * (C::ROWIMG + (C::TIMG ? C::RMIMG : C::ROWIMG)) + KT;
@@ -671,14 +672,14 @@ int sa_fwd(const void* q, const void* k, const void* v, const uint8_t* valid, vo
     int rc = set_lds_sa(kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(B * H * nqb), dim3(256), lds, st, (const T*)q, (const T*)k, (const T*)v, valid, (T*)out, lse, B, H,
-                       T_, nqb);
+                       T_, nqb, ldq);
     MMGL_CHECK_LAUNCH("selfattn_fwd");
     return MMGL_OK;
 }
 
 template <typename T, int D>
 int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, const uint8_t* valid,
-           void* dq, void* dk, void* dv, float* delta, int B, int H, int T_, hipStream_t st) {
+           void* dq, void* dk, void* dv, float* delta, int B, int H, int T_, int ldq, int ldg, hipStream_t st) {
     {
         const size_t total = (size_t)B * T_ * H * (D / 8);
         int blocks = (int)((total + 255) / 256);
@@ -694,7 +695,7 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
         int rc = set_lds_sa(kern, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(kern, dim3(B * H * nqb), dim3(256), lds, st, (const T*)dout, (const T*)q, (const T*)k, (const T*)v, lse,
-                           delta, valid, (T*)dq, B, H, T_, nqb);
+                           delta, valid, (T*)dq, B, H, T_, nqb, ldq, ldg);
         MMGL_CHECK_LAUNCH("selfattn_bwd_dq");
     }
     {
@@ -712,13 +713,13 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
             int rc = set_lds_sa(kern, lds_for(2));
             if (rc) return rc;
             hipLaunchKernelGGL(kern, dim3(B * H * nkb), dim3(256), lds_for(2), st, (const T*)dout, (const T*)q, (const T*)k, (const T*)v,
-                               lse, delta, valid, (T*)dk, (T*)dv, B, H, T_, nkb);
+                               lse, delta, valid, (T*)dk, (T*)dv, B, H, T_, nkb, ldq, ldg);
         } else {
             auto kern = selfattn_bwd_dkv_kernel<T, D, 1>;
             int rc = set_lds_sa(kern, lds_for(1));
             if (rc) return rc;
             hipLaunchKernelGGL(kern, dim3(B * H * nkb), dim3(128), lds_for(1), st, (const T*)dout, (const T*)q, (const T*)k, (const T*)v,
-                               lse, delta, valid, (T*)dk, (T*)dv, B, H, T_, nkb);
+                               lse, delta, valid, (T*)dk, (T*)dv, B, H, T_, nkb, ldq, ldg);
         }
         MMGL_CHECK_LAUNCH("selfattn_bwd_dkv");
     }
@@ -758,14 +759,21 @@ int sa_check(const char* who, int B, int H, int T, int D, int dtype) {
 
 }  // namespace
 
+static int sa_ld(const char* who, int& ld, int H, int D) {
+    if (ld == 0) ld = H * D;
+    MMGL_CHECK_ARG(ld >= H * D && ld % 8 == 0, "%s: row stride %d must be 0 (packed) or a multiple of 8 >= H*D = %d", who, ld, H * D);
+    return MMGL_OK;
+}
+
 extern "C" int mmgl_selfattn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out, float* lse,
-                                 int B, int H, int T, int D, int dtype, void* stream) {
+                                 int B, int H, int T, int D, int ld_qkv, int dtype, void* stream) {
     int rc = sa_check("mmgl_selfattn_fwd", B, H, T, D, dtype);
     if (rc) return rc;
     MMGL_CHECK_ARG(q && k && v && key_valid && out && lse, "mmgl_selfattn_fwd: null pointer");
+    if ((rc = sa_ld("mmgl_selfattn_fwd", ld_qkv, H, D))) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MMGL_BF16) { SA_DISPATCH(sa_fwd, bf16, q, k, v, key_valid, out, lse, B, H, T, st) }
-    SA_DISPATCH(sa_fwd, float, q, k, v, key_valid, out, lse, B, H, T, st)
+    if (dtype == MMGL_BF16) { SA_DISPATCH(sa_fwd, bf16, q, k, v, key_valid, out, lse, B, H, T, ld_qkv, st) }
+    SA_DISPATCH(sa_fwd, float, q, k, v, key_valid, out, lse, B, H, T, ld_qkv, st)
 }
 
 extern "C" size_t mmgl_selfattn_bwd_workspace(int B, int H, int T) {
@@ -775,15 +783,16 @@ extern "C" size_t mmgl_selfattn_bwd_workspace(int B, int H, int T) {
 
 extern "C" int mmgl_selfattn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse,
                                  const uint8_t* key_valid, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
-                                 int B, int H, int T, int D, int dtype, void* stream) {
+                                 int B, int H, int T, int D, int ld_qkv, int ld_dqkv, int dtype, void* stream) {
     int rc = sa_check("mmgl_selfattn_bwd", B, H, T, D, dtype);
     if (rc) return rc;
+    if ((rc = sa_ld("mmgl_selfattn_bwd", ld_qkv, H, D)) || (rc = sa_ld("mmgl_selfattn_bwd", ld_dqkv, H, D))) return rc;
     MMGL_CHECK_ARG(dout && q && k && v && out && lse && key_valid && dq && dk && dv && workspace, "mmgl_selfattn_bwd: null pointer");
     MMGL_CHECK_ARG(workspace_bytes >= mmgl_selfattn_bwd_workspace(B, H, T), "mmgl_selfattn_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* delta = (float*)workspace;
-    if (dtype == MMGL_BF16) { SA_DISPATCH(sa_bwd, bf16, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, st) }
-    SA_DISPATCH(sa_bwd, float, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, st)
+    if (dtype == MMGL_BF16) { SA_DISPATCH(sa_bwd, bf16, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_qkv, ld_dqkv, st) }
+    SA_DISPATCH(sa_bwd, float, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_qkv, ld_dqkv, st)
 }
 
 extern "C" int mmgl_encattn_fwd(const void* q, const void* k, const void* v, const int32_t* cu_seqlens, void* out, int nseq,

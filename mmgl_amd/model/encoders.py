@@ -119,10 +119,14 @@ class PackedTextEncoder:
         fused = self._fused.get([(l.attention.self.query, l.attention.self.key, l.attention.self.value) for l in layers],
                                 1.0 / math.sqrt(hid // H))
         first_rows = cu[:-1].long()
+        es = h.element_size()                # algorithmic work of one attention call (for the bench's per-kernel report)
+        work_all = dict(flops=4.0 * float((host[0].double() ** 2).sum()) * hid, bytes=4.0 * total * hid * es)
+        work_cls = dict(flops=4.0 * total * hid, bytes=2.0 * (total + n) * hid * es)
         for li, layer in enumerate(layers):
             last = li == len(layers) - 1
             qkv = F.linear(h, *fused[li])
-            ctx = ops.encoder_attention(qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:], cu, H, max_len, q_rows=1 if last else None)
+            ctx = ops.encoder_attention(qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:], cu, H, max_len, q_rows=1 if last else None,
+                                        work=work_cls if last else work_all)
             if last:                         # only the CLS rows are consumed downstream
                 ctx, h = ctx.index_select(0, first_rows), h.index_select(0, first_rows)
             ao = layer.attention.output
@@ -171,10 +175,14 @@ class PackedVisionEncoder:
         fused = self._fused.get([(l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj) for l in layers], 1.0 / math.sqrt(hid // H))
         first_rows = cu[:-1].long()
         y = ops.layer_norm(x, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, eps) if layers else None
+        es = x.element_size()
+        work_all = dict(flops=4.0 * n * S * S * hid, bytes=4.0 * n * S * hid * es)
+        work_cls = dict(flops=4.0 * n * S * hid, bytes=2.0 * (n * S + n) * hid * es)
         for li, layer in enumerate(layers):
             last = li == len(layers) - 1
             qkv = F.linear(y, *fused[li])
-            ctx = ops.encoder_attention(qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:], cu, H, S, q_rows=1 if last else None)
+            ctx = ops.encoder_attention(qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:], cu, H, S, q_rows=1 if last else None,
+                                        work=work_cls if last else work_all)
             if last:
                 ctx, x = ctx.index_select(0, first_rows), x.index_select(0, first_rows)
             a = F.linear(ctx, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias)

@@ -154,6 +154,23 @@ class MPTAttention(nn.Module):
         o = ops.xattn_core(q, k, v, key_valid, self.num_heads)
         return ops.linear(o, self.out_proj.weight, self.out_proj.bias), None, None
 
+    def _frozen_qkv(self):
+        """[3d, d] weight / [3d] bias = (q_proj * scaling | k_proj | v_proj) when the three projections are frozen (the
+        reference freezes the whole LM outside the cross-attention layers, :731-737), else None.  A derived copy: the
+        module's own parameters and state_dict stay as loaded; rebuilt when they change (load_state_dict, .bfloat16())."""
+        ps = (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.q_proj.bias, self.k_proj.bias, self.v_proj.bias)
+        if any(p is None or p.requires_grad for p in ps):
+            return None
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
+        cache = self.__dict__.get("_qkv_cache")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                w = torch.cat([ps[0].float() * self.scaling, ps[1].float(), ps[2].float()], 0).to(ps[0].dtype).contiguous()
+                b = torch.cat([ps[3].float() * self.scaling, ps[4].float(), ps[5].float()], 0).to(ps[0].dtype).contiguous()
+            cache = (key, (w, b))
+            self.__dict__["_qkv_cache"] = cache
+        return cache[1]
+
     # -- frozen OPT self-attention: stock torch ops with the reference's additive-mask semantics
     def _forward_self(self, hidden_states, attention_mask, layer_head_mask, output_attentions):
         bsz, tgt_len, _ = hidden_states.shape
@@ -163,6 +180,10 @@ class MPTAttention(nn.Module):
             # [B,H,T,T] scores, no head transposes.  MPTDecoder only hands this form over when key 0 of every sample is valid.
             if layer_head_mask is not None or output_attentions or (self.training and self.dropout > 0):
                 raise ValueError("layer_head_mask / output_attentions / attention dropout need the unfused self-attention path")
+            fused = self._frozen_qkv()
+            if fused is not None:            # frozen layer: one QKV GEMM forward, one dgrad GEMM backward, no gradient adds
+                o = ops.selfattn_core_fused(F.linear(hidden_states, *fused), attention_mask, H)
+                return self.out_proj(o), None, None
             q = self.q_proj(hidden_states) * self.scaling
             o = ops.selfattn_core(q, self.k_proj(hidden_states), self.v_proj(hidden_states), attention_mask, H)
             return self.out_proj(o), None, None

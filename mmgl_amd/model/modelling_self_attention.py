@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from transformers import AutoConfig, AutoModelForCausalLM, AutoModelForSeq2SeqLM, CLIPVisionModel, RobertaModel
 
 from .. import ops
+from .encoders import PackedTextEncoder, PackedVisionEncoder
 from .graph import GCN
 from .modelling_cross_attention import TextPooler
 
@@ -166,6 +167,15 @@ class SelfAttentionModel(nn.Module):
             self.lm.train()
 
     # ------------------------------------------------------------------------------------------ encoders
+    def _packed(self, model, cls):
+        """Padding-free HIP forward of a frozen encoder (encoders.py), or None when it does not cover `model`."""
+        if not getattr(self.args, "packed_encoders", True) or model is None:
+            return None
+        cache = self.__dict__.setdefault("_packed_cache", {})
+        if id(model) not in cache:
+            cache[id(model)] = cls(model) if cls.supports(model) else None
+        return cache[id(model)]
+
     def _project(self, pooled, linear, pos_emb, pos_ids, batch_size, n_tokens):
         embs = ops.linear(pooled.to(linear.weight.dtype).contiguous(), linear.weight, linear.bias)
         if pos_emb is not None and pos_ids is not None:
@@ -174,9 +184,13 @@ class SelfAttentionModel(nn.Module):
 
     def get_text_embs(self, input_ids, attention_mask, pos_ids=None):
         batch_size, neighbor_num, seq_len = input_ids.shape
+        ids, am = input_ids.reshape(-1, seq_len), attention_mask.reshape(-1, seq_len)
         with torch.no_grad():
-            out = self.text_model(input_ids=input_ids.reshape(-1, seq_len), attention_mask=attention_mask.reshape(-1, seq_len))
-        pooled = self.text_pooler(out.last_hidden_state)
+            packed = self._packed(self.text_model, PackedTextEncoder)
+            cls = packed.cls(ids, am) if packed is not None else None
+            if cls is None:
+                cls = self.text_model(input_ids=ids, attention_mask=am).last_hidden_state[:, 0]
+        pooled = self.text_pooler(cls.unsqueeze(1))
         pos = getattr(self, "text_position_embeddings", None) if self.position_type != "none" else None
         return self._project(pooled, self.text_embeddings, pos, pos_ids, batch_size, self.n_text_tokens)
 
@@ -184,7 +198,10 @@ class SelfAttentionModel(nn.Module):
         batch_size, neighbor_num, pixel, width, height = pixel_values.shape
         with torch.no_grad():
             pv = pixel_values.reshape(-1, pixel, width, height).to(next(self.visual_model.parameters()).dtype)
-            pooled = self.visual_model(pv).pooler_output
+            packed = self._packed(self.visual_model, PackedVisionEncoder)
+            pooled = packed.pooled(pv) if packed is not None else None
+            if pooled is None:
+                pooled = self.visual_model(pv).pooler_output
         pos = getattr(self, "visual_position_embeddings", None) if self.position_type != "none" else None
         return self._project(pooled, self.visual_embeddings, pos, pos_ids, batch_size, self.n_visual_tokens)
 

@@ -8,7 +8,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import dtype_code, lib, ptr, require_cuda, stream_ptr
+from ._lib import dtype_code, lib, ptr, ptr_off, require_cuda, stream_ptr
 
 
 # ------------------------------------------------------------------------------------------ attention core
@@ -70,7 +70,7 @@ class _SelfAttnCore(torch.autograd.Function):
         out = torch.empty_like(q)
         lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=q.device)
         _lib.call("mmgl_selfattn_fwd", dict(flops=2.0 * B * T * T * d, bytes=4.0 * B * T * d * q.element_size()),
-                  ptr(q), ptr(k), ptr(v), ptr(key_valid), ptr(out), ptr(lse), B, num_heads, T, D, dtype_code(q), stream_ptr())
+                  ptr(q), ptr(k), ptr(v), ptr(key_valid), ptr(out), ptr(lse), B, num_heads, T, D, 0, dtype_code(q), stream_ptr())
         ctx.save_for_backward(q, k, v, key_valid, out, lse)
         ctx.num_heads = num_heads
         return out
@@ -87,8 +87,58 @@ class _SelfAttnCore(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
         _lib.call("mmgl_selfattn_bwd", dict(flops=5.0 * B * T * T * d, bytes=8.0 * B * T * d * q.element_size()),
                   ptr(dout), ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(key_valid), ptr(dq), ptr(dk), ptr(dv), ptr(ws), nbytes,
-                  B, H, T, D, dtype_code(q), stream_ptr())
+                  B, H, T, D, 0, 0, dtype_code(q), stream_ptr())
         return dq, dk, dv, None, None
+
+
+class _SelfAttnFusedQKV(torch.autograd.Function):
+    """Same kernels, Q/K/V read in place from one fused projection output [B,T,3d] and dQ/dK/dV written into one
+    [B,T,3d] buffer (row stride 3d), so the projection's dgrad is ONE GEMM and autograd adds nothing up."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_valid, num_heads):
+        require_cuda(qkv, key_valid)
+        B, T, d3 = qkv.shape
+        d = d3 // 3
+        D = d // num_heads
+        qkv = qkv.contiguous()
+        out = torch.empty(B, T, d, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=qkv.device)
+        es = qkv.element_size()
+        _lib.call("mmgl_selfattn_fwd", dict(flops=2.0 * B * T * T * d, bytes=4.0 * B * T * d * es),
+                  ptr(qkv), ptr_off(qkv, d * es), ptr_off(qkv, 2 * d * es), ptr(key_valid), ptr(out), ptr(lse), B, num_heads, T, D, d3,
+                  dtype_code(qkv), stream_ptr())
+        ctx.save_for_backward(qkv, key_valid, out, lse)
+        ctx.num_heads = num_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, key_valid, out, lse = ctx.saved_tensors
+        H = ctx.num_heads
+        B, T, d3 = qkv.shape
+        d = d3 // 3
+        D = d // H
+        es = qkv.element_size()
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        nbytes = lib().mmgl_selfattn_bwd_workspace(B, H, T)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+        _lib.call("mmgl_selfattn_bwd", dict(flops=5.0 * B * T * T * d, bytes=8.0 * B * T * d * es),
+                  ptr(dout), ptr(qkv), ptr_off(qkv, d * es), ptr_off(qkv, 2 * d * es), ptr(out), ptr(lse), ptr(key_valid),
+                  ptr(dqkv), ptr_off(dqkv, d * es), ptr_off(dqkv, 2 * d * es), ptr(ws), nbytes, B, H, T, D, d3, d3, dtype_code(qkv), stream_ptr())
+        return dqkv, None, None
+
+
+def selfattn_core_fused(qkv, key_valid, num_heads):
+    """selfattn_core over a fused projection output: qkv [B,T,3d] = [q*scale | k | v] along the last dim."""
+    if qkv.dim() != 3 or qkv.shape[2] % (3 * num_heads):
+        raise ValueError(f"selfattn_core_fused: qkv{tuple(qkv.shape)} is not [B, T, 3*H*D] for H={num_heads}")
+    if key_valid.shape != qkv.shape[:2]:
+        raise ValueError(f"Attention mask should be of size {tuple(qkv.shape[:2])}, but is {tuple(key_valid.shape)}")
+    if key_valid.dtype != torch.uint8:
+        key_valid = key_valid.to(torch.uint8)
+    return _SelfAttnFusedQKV.apply(qkv, key_valid.contiguous(), num_heads)
 
 
 def selfattn_core(q, k, v, key_valid, num_heads):
@@ -430,7 +480,7 @@ def adamw_step_(param, master, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
 ACT_CODES = {"relu": 1, "gelu": 2, "quick_gelu": 3, "gelu_new": 4, "gelu_pytorch_tanh": 4, "gelu_fast": 4}
 
 
-def encoder_attention(q, k, v, cu_seqlens, num_heads, max_len, q_rows=None):
+def encoder_attention(q, k, v, cu_seqlens, num_heads, max_len, q_rows=None, work=None):
     """Bidirectional attention over packed sequences (no padding rows exist).  q, k, v: [ntok, H*D] views with a common
     row stride (e.g. the three column slices of a fused-QKV output); q pre-scaled by D^-1/2; cu_seqlens int32 [nseq+1].
     Returns [ntok, H*D]; with q_rows < max_len only the first q_rows rows of every sequence are written.
@@ -448,7 +498,7 @@ def encoder_attention(q, k, v, cu_seqlens, num_heads, max_len, q_rows=None):
     nseq = cu_seqlens.numel() - 1
     if nseq <= 0 or ntok == 0:
         return out
-    _lib.call("mmgl_encattn_fwd", None, ptr(q), ptr(k), ptr(v), ptr(cu_seqlens), ptr(out), nseq, num_heads, hd // num_heads, ld, hd,
+    _lib.call("mmgl_encattn_fwd", work, ptr(q), ptr(k), ptr(v), ptr(cu_seqlens), ptr(out), nseq, num_heads, hd // num_heads, ld, hd,
               int(max_len), int(max_len if q_rows is None else q_rows), dtype_code(q), stream_ptr())
     return out
 
@@ -464,7 +514,7 @@ def add_layer_norm(x, res, gamma, beta, eps, return_sum=False):
     s = torch.empty_like(x2) if return_sum else None
     g, b = gamma.to(x.dtype).contiguous(), beta.to(x.dtype).contiguous()
     if x2.shape[0]:
-        _lib.call("mmgl_add_layernorm_fwd", None, ptr(x2), ptr(r2), ptr(g), ptr(b), ptr(s), ptr(y), x2.shape[0], cols, float(eps),
+        _lib.call("mmgl_add_layernorm_fwd", dict(bytes=(4.0 if return_sum else 3.0) * x2.numel() * x2.element_size()), ptr(x2), ptr(r2), ptr(g), ptr(b), ptr(s), ptr(y), x2.shape[0], cols, float(eps),
                   dtype_code(x2), stream_ptr())
     return (s.view(x.shape), y.view(x.shape)) if return_sum else y.view(x.shape)
 
@@ -476,5 +526,5 @@ def activation_(x, name):
         raise ValueError(f"activation_: unsupported activation {name!r}")
     if not x.is_contiguous():
         raise ValueError("activation_: tensor must be contiguous")
-    _lib.call("mmgl_activation_fwd", None, ptr(x), ptr(x), x.numel(), ACT_CODES[name], dtype_code(x), stream_ptr())
+    _lib.call("mmgl_activation_fwd", dict(bytes=2.0 * x.numel() * x.element_size()), ptr(x), ptr(x), x.numel(), ACT_CODES[name], dtype_code(x), stream_ptr())
     return x

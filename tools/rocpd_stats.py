@@ -4,7 +4,12 @@ import csv
 import sqlite3
 import sys
 
+import glob
+import os
+
 db, out = sys.argv[1], sys.argv[2]
+if os.path.isdir(db):                       # the -d directory of the rocprofv3 run
+    db = sorted(glob.glob(os.path.join(db, "**", "*.db"), recursive=True))[0]
 con = sqlite3.connect(db)
 rows = list(con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
 with open(out, "w", newline="") as f:
