@@ -215,13 +215,24 @@ int mmgl_adamw_step(void* param, float* master, const void* grad, float* exp_avg
  *   of a fused-QKV GEMM output are fine: ld_in = 3*H*D) and of out [ntok, ld_out]; head h uses columns h*D..h*D+D-1.
  *   q must be pre-scaled by D^-1/2.  max_len = longest sequence (host knows it from the packing); q_rows = number of
  *   leading query rows per sequence to compute (pass max_len for all, 1 for the CLS row only).  No padding token is read.
- * mmgl_add_layernorm_fwd: s = x + res (rounded to dtype), y = LayerNorm(s); sum_out (may be NULL) receives s.
+ * mmgl_add_layernorm_fwd: s = x + res (rounded to dtype), y = LayerNorm(s); sum_out (may be NULL) receives s; mean, rstd
+ *   [rows] fp32 may be NULL (inference).  Also the residual-add + LayerNorm pair of the decoder layers
+ *   (modelling_cross_attention.py:334-350: `hidden = residual + h` followed by the next LayerNorm) when they are saved.
+ *   p_drop > 0: s = res + dropout(x) (inverted dropout, the counter hash of mmgl_gated_residual_fwd under `seed`).
+ * mmgl_add_layernorm_bwd: given dy (grad of y) and dsum (grad arriving on s itself, may be NULL),
+ *   dres = LayerNorm'(dy) + dsum; with p_drop == 0 that is also the gradient of x (dx ignored, may be NULL), otherwise
+ *   dx = dres * keep / (1 - p).  dgamma/dbeta fp32 optional (workspace as for mmgl_layernorm_bwd).
  * mmgl_activation_fwd: y = act(x) elementwise, in place allowed; act 1 relu, 2 gelu (erf), 3 quick_gelu, 4 gelu (tanh).
  */
 int mmgl_encattn_fwd(const void* q, const void* k, const void* v, const int32_t* cu_seqlens, void* out, int nseq,
                      int H, int D, int ld_in, int ld_out, int max_len, int q_rows, int dtype, void* stream);
 int mmgl_add_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* sum_out,
-                           void* y, int rows, int cols, float eps, int dtype, void* stream);
+                           void* y, float* mean, float* rstd, int rows, int cols, float eps, float p_drop, uint64_t seed,
+                           int dtype, void* stream);
+int mmgl_add_layernorm_bwd(const void* dy, const void* dsum, const void* sum, const void* gamma, const float* mean,
+                           const float* rstd, void* dres, void* dx, float* dgamma, float* dbeta, void* workspace,
+                           size_t workspace_bytes, int rows, int cols, float p_drop, uint64_t seed, int dtype,
+                           void* stream);
 int mmgl_activation_fwd(const void* x, void* y, size_t n, int act, int dtype, void* stream);
 
 #ifdef __cplusplus

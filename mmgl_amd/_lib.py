@@ -55,7 +55,8 @@ SIGNATURES = {
     "mmgl_position_ids": (I, [P, P, I, I, P]),
     "mmgl_adamw_step": (I, [P, P, P, P, P, Z, F, F, F, F, F, I, F, I, P]),
     "mmgl_encattn_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
-    "mmgl_add_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, I, P]),
+    "mmgl_add_layernorm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, F, F, U, I, P]),
+    "mmgl_add_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, F, U, I, P]),
     "mmgl_activation_fwd": (I, [P, P, Z, I, I, P]),
 }
 

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void gated_fwd_kernel(const T* __restrict__ re
         for (int j = 0; j < VN; ++j) {
             float a = (float)xv[j];
             if (p > 0.f && mmgl_hash32(seed, i * VN + j) < thr) a = 0.f;
-            o[j] = (T)((float)r[j] + sc * a);
+            o[j] = (T)fmaf(sc, a, (float)r[j]);
         }
         ((V*)y)[i] = o;
     }
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void gated_fwd_kernel(const T* __restrict__ re
         for (size_t i = nvec * VN; i < n; ++i) {
             float a = (float)x[i];
             if (p > 0.f && mmgl_hash32(seed, i) < thr) a = 0.f;
-            y[i] = (T)((float)res[i] + sc * a);
+            y[i] = (T)fmaf(sc, a, (float)res[i]);
         }
 }
 

@@ -35,13 +35,15 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
                                                        const T* __restrict__ gamma, const T* __restrict__ beta,
                                                        T* __restrict__ sum_out, T* __restrict__ y,
                                                        float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                       int cols, float eps) {
+                                                       int cols, float eps, float p, uint64_t seed) {
     typedef typename Vec<T>::type V;
     constexpr int VN = Vec<T>::N;
     __shared__ float red[4];
     const int rpb = 256 / TPR;
     const int tr = threadIdx.x % TPR, rib = threadIdx.x / TPR;
     const int nchunks = cols / VN;
+    const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const uint32_t thr = (uint32_t)fminf(p * 4294967296.f, 4294967295.f);
     for (int row0 = blockIdx.x * rpb; row0 < rows; row0 += gridDim.x * rpb) {
         const int row = row0 + rib;
         const bool live = row < rows;
@@ -54,8 +56,17 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
                 V v = *(const V*)(x + (size_t)row * cols + c * VN);
                 if (res) {                                    // fused residual add: the sum is rounded to T like torch's x + r
                     const V r = *(const V*)(res + (size_t)row * cols + c * VN);
+                    if (p > 0.f) {                            // s = res + dropout(x): same counter hash as mmgl_gated_residual_fwd
+                        const uint64_t e0 = (uint64_t)row * cols + (uint64_t)c * VN;
 #pragma unroll
-                    for (int j = 0; j < VN; ++j) v[j] = (T)((float)v[j] + (float)r[j]);
+                        for (int j = 0; j < VN; ++j) {
+                            const float a = (mmgl_hash32(seed, e0 + j) < thr) ? 0.f : (float)v[j];
+                            v[j] = (T)fmaf(keep_scale, a, (float)r[j]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < VN; ++j) v[j] = (T)((float)v[j] + (float)r[j]);
+                    }
                     if (sum_out) *(V*)(sum_out + (size_t)row * cols + c * VN) = v;
                 }
 #pragma unroll
@@ -103,11 +114,14 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
     }
 }
 
-template <typename T, int TPR, int NV, bool RMS>
+// MODE bit 0: RMSNorm (no mean); bit 1: accumulate the dgamma / dbeta column partials (skipped for frozen affines)
+template <typename T, int TPR, int NV, int MODE>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                        const T* __restrict__ gamma, const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, T* __restrict__ dx,
-                                                       float* __restrict__ part, int rows, int cols) {
+                                                       const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                       T* __restrict__ dx, T* __restrict__ dx_drop, float* __restrict__ part,
+                                                       int rows, int cols, float p, uint64_t seed) {
+    constexpr bool RMS = (MODE & 1) != 0, PARAMS = (MODE & 2) != 0;
     typedef typename Vec<T>::type V;
     constexpr int VN = Vec<T>::N;
     __shared__ float red[4];
@@ -141,8 +155,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ dy,
                 for (int j = 0; j < VN; ++j) {
                     const float h = ((float)xv[j] - mu) * rs;
                     const float d = (float)dv[j];
-                    dg[i][j] += d * h;
-                    dbt[i][j] += d;
+                    if constexpr (PARAMS) { dg[i][j] += d * h; dbt[i][j] += d; }
                     xh[i][j] = h;
                     gy[i][j] = d * gm[i][j];
                     s1 += gy[i][j];
@@ -161,13 +174,28 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ dy,
             const int c = tr + i * TPR;
             if (live && c < nchunks) {
                 V o;
+                if (dres) {                                   // gradient arriving on the residual stream (x + res) itself
+                    const V dr = *(const V*)(dres + (size_t)row * cols + c * VN);
 #pragma unroll
-                for (int j = 0; j < VN; ++j) o[j] = (T)(rs * (gy[i][j] - m1 - xh[i][j] * m2));
+                    for (int j = 0; j < VN; ++j) o[j] = (T)(rs * (gy[i][j] - m1 - xh[i][j] * m2) + (float)dr[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VN; ++j) o[j] = (T)(rs * (gy[i][j] - m1 - xh[i][j] * m2));
+                }
                 *(V*)(dx + (size_t)row * cols + c * VN) = o;
+                if (dx_drop) {                                // gradient of the dropped-out branch x of s = res + dropout(x)
+                    const float ks = 1.f / (1.f - p);
+                    const uint32_t thr = (uint32_t)fminf(p * 4294967296.f, 4294967295.f);
+                    const uint64_t e0 = (uint64_t)row * cols + (uint64_t)c * VN;
+                    V od;
+#pragma unroll
+                    for (int j = 0; j < VN; ++j) od[j] = (mmgl_hash32(seed, e0 + j) < thr) ? (T)0.f : (T)((float)o[j] * ks);
+                    *(V*)(dx_drop + (size_t)row * cols + c * VN) = od;
+                }
             }
         }
     }
-    if (part) {
+    if (PARAMS && part) {
         // rows of one block that share a column are different threads (rib): fold them through LDS-free atomics? no:
         // write one partial row per (block, rib) -> deterministic second pass.
         float* pg = part + ((size_t)(blockIdx.x * rpb + rib)) * cols * 2;
@@ -220,7 +248,7 @@ template <typename T> int geometry(const char* who, int rows, int cols, Geo& g) 
     MMGL_CHECK_ARG(rows > 0 && cols > 0, "%s: rows/cols must be positive", who);
     if (cols % VN) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "%s: cols=%d must be a multiple of %d", who, cols, VN);
     const int nchunks = cols / VN;
-    g.tpr = (nchunks <= 64 * 2) ? 64 : 256;
+    g.tpr = (nchunks <= 64 * 4) ? 64 : 256;      // one wave per row while the row fits 4 chunks per lane: no block barriers
     g.nv = (nchunks + g.tpr - 1) / g.tpr;
     if (g.nv > NVMAX) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "%s: cols=%d exceeds the register-resident row limit %d", who, cols,
                                 256 * NVMAX * VN);
@@ -237,7 +265,8 @@ int bwd_blocks(int rows, int rpb) {
     do {                                                                                           \
         if (g.tpr == 64) {                                                                         \
             if (g.nv == 1) hipLaunchKernelGGL((KERN<T, 64, 1, RMS>), __VA_ARGS__);                 \
-            else hipLaunchKernelGGL((KERN<T, 64, 2, RMS>), __VA_ARGS__);                           \
+            else if (g.nv == 2) hipLaunchKernelGGL((KERN<T, 64, 2, RMS>), __VA_ARGS__);            \
+            else hipLaunchKernelGGL((KERN<T, 64, 4, RMS>), __VA_ARGS__);                           \
         } else {                                                                                   \
             if (g.nv == 1) hipLaunchKernelGGL((KERN<T, 256, 1, RMS>), __VA_ARGS__);                \
             else if (g.nv == 2) hipLaunchKernelGGL((KERN<T, 256, 2, RMS>), __VA_ARGS__);           \
@@ -247,34 +276,40 @@ int bwd_blocks(int rows, int rpb) {
 
 template <typename T, bool RMS>
 int norm_fwd(const char* who, const void* x, const void* res, const void* gamma, const void* beta, void* sum_out, void* y,
-             float* mean, float* rstd, int rows, int cols, float eps, hipStream_t st) {
+             float* mean, float* rstd, int rows, int cols, float eps, hipStream_t st, float p = 0.f, uint64_t seed = 0) {
     Geo g;
     int rc = geometry<T>(who, rows, cols, g);
     if (rc) return rc;
     int blocks = (rows + g.rpb - 1) / g.rpb;
     if (blocks > 8192) blocks = 8192;
     NORM_DISPATCH(norm_fwd_kernel, T, RMS, g, dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)res, (const T*)gamma,
-                  (const T*)beta, (T*)sum_out, (T*)y, mean, rstd, rows, cols, eps);
+                  (const T*)beta, (T*)sum_out, (T*)y, mean, rstd, rows, cols, eps, p, seed);
     MMGL_CHECK_LAUNCH(who);
     return MMGL_OK;
 }
 
 template <typename T, bool RMS>
 int norm_bwd(const char* who, const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
-             void* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int rows, int cols, hipStream_t st) {
+             const void* dres, void* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int rows, int cols, hipStream_t st,
+             void* dx_drop = nullptr, float p = 0.f, uint64_t seed = 0) {
     Geo g;
     int rc = geometry<T>(who, rows, cols, g);
     if (rc) return rc;
-    const int blocks = bwd_blocks(rows, g.rpb);
     const bool want = dgamma || dbeta;
+    int blocks = bwd_blocks(rows, g.rpb);              // capped: every block owns a partial row of column sums
+    if (!want) { blocks = (rows + g.rpb - 1) / g.rpb; if (blocks > 8192) blocks = 8192; }
     float* part = nullptr;
     if (want) {
         MMGL_CHECK_ARG(ws && ws_bytes >= (size_t)blocks * g.rpb * cols * 2 * sizeof(float),
                        "%s: workspace too small (%zu B)", who, ws_bytes);
         part = (float*)ws;
     }
-    NORM_DISPATCH(norm_bwd_kernel, T, RMS, g, dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x,
-                  (const T*)gamma, mean, rstd, (T*)dx, part, rows, cols);
+    if (want)
+        NORM_DISPATCH(norm_bwd_kernel, T, (RMS ? 3 : 2), g, dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x,
+                      (const T*)gamma, mean, rstd, (const T*)dres, (T*)dx, (T*)dx_drop, part, rows, cols, p, seed);
+    else
+        NORM_DISPATCH(norm_bwd_kernel, T, (RMS ? 1 : 0), g, dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x,
+                      (const T*)gamma, mean, rstd, (const T*)dres, (T*)dx, (T*)dx_drop, part, rows, cols, p, seed);
     MMGL_CHECK_LAUNCH(who);
     if (want) {
         hipLaunchKernelGGL(norm_param_reduce_kernel, dim3((2 * cols + 31) / 32), dim3(256), 0, st, part, dgamma, dbeta,
@@ -304,14 +339,32 @@ extern "C" int mmgl_layernorm_fwd(const void* x, const void* gamma, const void* 
 }
 
 extern "C" int mmgl_add_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* sum_out,
-                                      void* y, int rows, int cols, float eps, int dtype, void* stream) {
+                                      void* y, float* mean, float* rstd, int rows, int cols, float eps, float p_drop,
+                                      uint64_t seed, int dtype, void* stream) {
     MMGL_CHECK_ARG(x && res && y, "mmgl_add_layernorm_fwd: null pointer");
+    MMGL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mmgl_add_layernorm_fwd: dropout p=%g outside [0,1)", p_drop);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MMGL_BF16)
-        return norm_fwd<bf16, false>("mmgl_add_layernorm_fwd", x, res, gamma, beta, sum_out, y, nullptr, nullptr, rows, cols, eps, st);
+        return norm_fwd<bf16, false>("mmgl_add_layernorm_fwd", x, res, gamma, beta, sum_out, y, mean, rstd, rows, cols, eps, st, p_drop, seed);
     if (dtype == MMGL_F32)
-        return norm_fwd<float, false>("mmgl_add_layernorm_fwd", x, res, gamma, beta, sum_out, y, nullptr, nullptr, rows, cols, eps, st);
+        return norm_fwd<float, false>("mmgl_add_layernorm_fwd", x, res, gamma, beta, sum_out, y, mean, rstd, rows, cols, eps, st, p_drop, seed);
     MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_add_layernorm_fwd: bad dtype %d", dtype);
+}
+
+extern "C" int mmgl_add_layernorm_bwd(const void* dy, const void* dsum, const void* sum, const void* gamma, const float* mean,
+                                      const float* rstd, void* dres, void* dx, float* dgamma, float* dbeta, void* workspace,
+                                      size_t workspace_bytes, int rows, int cols, float p_drop, uint64_t seed, int dtype,
+                                      void* stream) {
+    MMGL_CHECK_ARG(dy && sum && mean && rstd && dres, "mmgl_add_layernorm_bwd: null pointer");
+    MMGL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mmgl_add_layernorm_bwd: dropout p=%g outside [0,1)", p_drop);
+    MMGL_CHECK_ARG(p_drop == 0.f || dx, "mmgl_add_layernorm_bwd: dx is required when p_drop > 0");
+    hipStream_t st = (hipStream_t)stream;
+    void* dxd = p_drop > 0.f ? dx : nullptr;
+    if (dtype == MMGL_BF16)
+        return norm_bwd<bf16, false>("mmgl_add_layernorm_bwd", dy, sum, gamma, mean, rstd, dsum, dres, dgamma, dbeta, workspace, workspace_bytes, rows, cols, st, dxd, p_drop, seed);
+    if (dtype == MMGL_F32)
+        return norm_bwd<float, false>("mmgl_add_layernorm_bwd", dy, sum, gamma, mean, rstd, dsum, dres, dgamma, dbeta, workspace, workspace_bytes, rows, cols, st, dxd, p_drop, seed);
+    MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_add_layernorm_bwd: bad dtype %d", dtype);
 }
 
 extern "C" int mmgl_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
@@ -320,9 +373,9 @@ extern "C" int mmgl_layernorm_bwd(const void* dy, const void* x, const void* gam
     MMGL_CHECK_ARG(dy && x && mean && rstd && dx, "mmgl_layernorm_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MMGL_BF16)
-        return norm_bwd<bf16, false>("mmgl_layernorm_bwd", dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, workspace_bytes, rows, cols, st);
+        return norm_bwd<bf16, false>("mmgl_layernorm_bwd", dy, x, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, workspace, workspace_bytes, rows, cols, st);
     if (dtype == MMGL_F32)
-        return norm_bwd<float, false>("mmgl_layernorm_bwd", dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, workspace_bytes, rows, cols, st);
+        return norm_bwd<float, false>("mmgl_layernorm_bwd", dy, x, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, workspace, workspace_bytes, rows, cols, st);
     MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_layernorm_bwd: bad dtype %d", dtype);
 }
 
@@ -341,8 +394,8 @@ extern "C" int mmgl_rmsnorm_bwd(const void* dy, const void* x, const void* gamma
     MMGL_CHECK_ARG(dy && x && rstd && dx, "mmgl_rmsnorm_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MMGL_BF16)
-        return norm_bwd<bf16, true>("mmgl_rmsnorm_bwd", dy, x, gamma, nullptr, rstd, dx, dgamma, nullptr, workspace, workspace_bytes, rows, cols, st);
+        return norm_bwd<bf16, true>("mmgl_rmsnorm_bwd", dy, x, gamma, nullptr, rstd, nullptr, dx, dgamma, nullptr, workspace, workspace_bytes, rows, cols, st);
     if (dtype == MMGL_F32)
-        return norm_bwd<float, true>("mmgl_rmsnorm_bwd", dy, x, gamma, nullptr, rstd, dx, dgamma, nullptr, workspace, workspace_bytes, rows, cols, st);
+        return norm_bwd<float, true>("mmgl_rmsnorm_bwd", dy, x, gamma, nullptr, rstd, nullptr, dx, dgamma, nullptr, workspace, workspace_bytes, rows, cols, st);
     MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_rmsnorm_bwd: bad dtype %d", dtype);
 }

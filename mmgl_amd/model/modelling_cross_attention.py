@@ -19,6 +19,7 @@ Deliberate deviations from the reference (all documented in DESIGN.md, SURVEY.md
 GPU only: there is no CPU fallback (ops raise if tensors are not on the device).
 """
 import math
+import os
 from typing import List, Optional, Tuple, Union
 
 import torch
@@ -221,6 +222,23 @@ class MPTAttention(nn.Module):
         return self._forward_self(hidden_states, attention_mask, layer_head_mask, output_attentions)
 
 
+_FUSE_ADD_LN = os.environ.get("MMGL_FUSE_ADD_LN", "1") != "0"     # A/B switch for the fused residual + LayerNorm pairs
+
+
+class _Deferred:
+    """A layer output whose last residual add (`hidden = residual + branch`, reference :358-359) has not been done yet:
+    the next pre-LN layer (or the final LayerNorm) performs it inside its first LayerNorm kernel (ops.add_layer_norm_pair).
+    Internal to MPTDecoder's layer loop; anything else sees tensors (`_materialize`)."""
+    __slots__ = ("residual", "branch", "p_drop", "training")
+
+    def __init__(self, residual, branch, p_drop=0.0, training=False):
+        self.residual, self.branch, self.p_drop, self.training = residual, branch, p_drop, training
+
+
+def _materialize(h, *_):
+    return ops.gated_residual(h.residual, h.branch, None, h.p_drop, h.training) if isinstance(h, _Deferred) else h
+
+
 class MPTDecoderLayer(nn.Module):
     """OPT decoder layer; with cross_attention=True the Flamingo-style gated block (reference :278-375)."""
 
@@ -269,31 +287,58 @@ class MPTDecoderLayer(nn.Module):
             h = self._ln(self.final_layer_norm, h)
         return h, attn_w
 
-    def _forward_self(self, h, attention_mask, layer_head_mask, output_attentions):
-        """Frozen OPT layer: GEMMs and the attention core are torch (hipBLASLt / SDPA) in this round; the row ops around
-        them -- LayerNorm and dropout+residual -- already run on this repo's HIP kernels (one pass each instead of 2-3)."""
+    def _forward_self(self, h, attention_mask, layer_head_mask, output_attentions, defer_residual=False):
+        """Frozen OPT layer: GEMMs are library calls (hipBLASLt); attention (ops.selfattn_core*), LayerNorm, dropout +
+        residual run on this repo's HIP kernels.  Every `residual + dropout(branch)` is folded into the LayerNorm that
+        follows it (ops.add_layer_norm_pair: one forward and one backward kernel per pair); the layer's last add can be
+        left to the next layer's first LayerNorm (`defer_residual`, see _Deferred)."""
+        pre = self.do_layer_norm_before
+        ln1, ln2 = self.self_attn_layer_norm, self.final_layer_norm
+        fuse = isinstance(h, _Deferred) or (h.is_cuda and _FUSE_ADD_LN)
+        pair = lambda x, r, ln: ops.add_layer_norm_pair(x, r, ln.weight, ln.bias, ln.eps, self.dropout, self.training)
+        if isinstance(h, _Deferred):
+            if pre:
+                h, x = ops.add_layer_norm_pair(h.branch, h.residual, ln1.weight, ln1.bias, ln1.eps, h.p_drop, h.training)
+            else:
+                h = x = _materialize(h)
+        else:
+            x = self._ln(ln1, h) if pre else h
         residual = h
-        x = self._ln(self.self_attn_layer_norm, h) if self.do_layer_norm_before else h
         a, attn_w, _ = self.self_attn(x, attention_mask=attention_mask, layer_head_mask=layer_head_mask,
                                       output_attentions=output_attentions)
-        h = ops.gated_residual(residual, a, None, self.dropout, self.training)
-        if not self.do_layer_norm_before:
-            h = self._ln(self.self_attn_layer_norm, h)
+        if fuse and pre:
+            h, x = pair(a, residual, ln2)
+        elif fuse:
+            _, h = pair(a, residual, ln1)                                                   # post-LN: h = LN(residual + a)
+            x = h
+        else:
+            h = ops.gated_residual(residual, a, None, self.dropout, self.training)
+            if not pre:
+                h = self._ln(ln1, h)
+            x = self._ln(ln2, h) if pre else h
         residual = h
-        x = self._ln(self.final_layer_norm, h) if self.do_layer_norm_before else h
-        x = self.fc2(self.activation_fn(self.fc1(x)))
+        if (self.activation_name == "relu" and x.is_cuda and not self.fc1.weight.requires_grad and self.fc1.bias is not None
+                and not self.fc1.bias.requires_grad):
+            x = self.fc2(ops.frozen_linear_relu(x, self.fc1.weight, self.fc1.bias))
+        else:
+            x = self.fc2(self.activation_fn(self.fc1(x)))
+        if fuse and pre and defer_residual:
+            return _Deferred(residual, x, self.dropout, self.training), attn_w
+        if fuse and not pre:
+            _, h = pair(x, residual, ln2)
+            return h, attn_w
         h = ops.gated_residual(residual, x, None, self.dropout, self.training)
-        if not self.do_layer_norm_before:
-            h = self._ln(self.final_layer_norm, h)
+        if not pre:
+            h = self._ln(ln2, h)
         return h, attn_w
 
     def forward(self, hidden_states, attention_mask=None, neighbor_embeds=None, neighbor_attention_mask=None,
-                layer_head_mask=None, past_key_value=None, output_attentions=False, use_cache=False):
+                layer_head_mask=None, past_key_value=None, output_attentions=False, use_cache=False, defer_residual=False):
         if self.cross_attention:
-            h, attn_w = self._forward_cross(hidden_states, neighbor_embeds, neighbor_attention_mask, layer_head_mask,
+            h, attn_w = self._forward_cross(_materialize(hidden_states), neighbor_embeds, neighbor_attention_mask, layer_head_mask,
                                             output_attentions)
         else:
-            h, attn_w = self._forward_self(hidden_states, attention_mask, layer_head_mask, output_attentions)
+            h, attn_w = self._forward_self(hidden_states, attention_mask, layer_head_mask, output_attentions, defer_residual)
         outputs = (h,)
         if output_attentions:
             outputs += (attn_w,)
@@ -425,6 +470,7 @@ class MPTDecoder(MPTPreTrainedModel):
             raise ValueError(f"The `head_mask` should be specified for {len(self.layers)} layers, but it is for"
                              f" {head_mask.size()[0]}.")
 
+        defer = inputs_embeds.is_cuda and not output_hidden_states and _FUSE_ADD_LN
         for idx, decoder_layer in enumerate(self.layers):
             if output_hidden_states:
                 all_hidden_states += (hidden_states,)
@@ -433,9 +479,9 @@ class MPTDecoder(MPTPreTrainedModel):
                     continue
             lhm = head_mask[idx] if head_mask is not None else None
             layer_outputs = decoder_layer(hidden_states, attention_mask=causal_attention_mask, layer_head_mask=lhm,
-                                          output_attentions=output_attentions)
+                                          output_attentions=output_attentions, defer_residual=defer)
             if self.cross_attention and neighbor_embeds is not None and (idx + 1) % self.neighbor_layer_wise == 0:
-                hidden_states = layer_outputs[0]
+                hidden_states = _materialize(layer_outputs[0])
                 neighbor_idx = (idx + 1) // self.neighbor_layer_wise - 1
                 layer_outputs = self.neighbor_layers[neighbor_idx](
                     hidden_states, attention_mask=causal_attention_mask, neighbor_embeds=neighbor_embeds,
@@ -447,7 +493,13 @@ class MPTDecoder(MPTPreTrainedModel):
                 all_self_attns += (layer_outputs[1],)
 
         if self.final_layer_norm is not None:
-            hidden_states = self.final_layer_norm(hidden_states)
+            fln = self.final_layer_norm
+            if isinstance(hidden_states, _Deferred):
+                _, hidden_states = ops.add_layer_norm_pair(hidden_states.branch, hidden_states.residual, fln.weight, fln.bias, fln.eps,
+                                                           hidden_states.p_drop, hidden_states.training)
+            else:
+                hidden_states = fln(hidden_states)
+        hidden_states = _materialize(hidden_states)
         if self.project_out is not None:
             hidden_states = self.project_out(hidden_states)
         if output_hidden_states:

@@ -204,6 +204,72 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     return _LayerNorm.apply(x, gamma, beta, float(eps))
 
 
+class _AddLayerNorm(torch.autograd.Function):
+    """(s, y) = (res + dropout(x), LayerNorm(s)) in one pass; backward folds the gradient arriving on s into the LayerNorm
+    backward kernel, which writes the gradient of res and (when dropout is active) of x -- no separate residual kernels,
+    no autograd accumulation add."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, p_drop, seed):
+        require_cuda(x, res)
+        shape = x.shape
+        cols = shape[-1]
+        x2, r2 = x.contiguous().view(-1, cols), res.contiguous().view(-1, cols)
+        rows = x2.shape[0]
+        s, y = torch.empty_like(x2), torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        g = None if gamma is None else gamma.to(x.dtype).contiguous()
+        b = None if beta is None else beta.to(x.dtype).contiguous()
+        _lib.call("mmgl_add_layernorm_fwd", dict(bytes=4.0 * rows * cols * x.element_size()), ptr(x2), ptr(r2), ptr(g), ptr(b), ptr(s), ptr(y),
+                  ptr(mean), ptr(rstd), rows, cols, eps, p_drop, seed, dtype_code(x), stream_ptr())
+        ctx.save_for_backward(s, g, mean, rstd)
+        ctx.shape, ctx.p, ctx.seed = shape, p_drop, seed
+        ctx.pgrad = (gamma is not None and gamma.requires_grad, beta is not None and beta.requires_grad)
+        ctx.pdtype = None if gamma is None else gamma.dtype
+        return s.view(shape), y.view(shape)
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        s, g, mean, rstd = ctx.saved_tensors
+        rows, cols = s.shape
+        p = ctx.p
+        if dy is None:                                        # only the residual stream was used downstream
+            if p == 0.0:
+                return ds, ds, None, None, None, None, None
+            dy = torch.zeros_like(ds)
+        dy2 = dy.contiguous().view(rows, cols)
+        ds2 = None if ds is None else ds.contiguous().view(rows, cols)
+        dres = torch.empty_like(s)
+        dx = torch.empty_like(s) if p > 0.0 else None
+        want = any(ctx.pgrad)
+        dgamma = torch.empty(cols, dtype=torch.float32, device=s.device) if want else None
+        dbeta = torch.empty(cols, dtype=torch.float32, device=s.device) if want else None
+        nbytes = lib().mmgl_norm_bwd_workspace(rows, cols) if want else 0
+        ws = _ws(nbytes, s.device)
+        nt = 3.0 + (ds2 is not None) + (dx is not None)
+        _lib.call("mmgl_add_layernorm_bwd", dict(bytes=nt * rows * cols * s.element_size()), ptr(dy2), ptr(ds2), ptr(s), ptr(g), ptr(mean),
+                  ptr(rstd), ptr(dres), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), rows, cols, p, ctx.seed, dtype_code(s),
+                  stream_ptr())
+        dres = dres.view(ctx.shape)
+        dx = dres if dx is None else dx.view(ctx.shape)
+        dg = dgamma.to(ctx.pdtype) if ctx.pgrad[0] else None
+        db = dbeta.to(ctx.pdtype) if ctx.pgrad[1] else None
+        return dx, dres, dg, db, None, None, None
+
+
+def add_layer_norm_pair(x, res, gamma, beta, eps=1e-5, p_drop=0.0, training=False, seed=None):
+    """Differentiable (s, LayerNorm(s)) with s = res + dropout(x): the `hidden = residual + dropout(h)` / next-LayerNorm
+    pair of a decoder layer (reference model/modelling_cross_attention.py:332-350) as one forward and one backward
+    kernel.  Dropout uses the same counter hash of (seed, element index) as gated_residual."""
+    if x.shape != res.shape:
+        raise ValueError(f"add_layer_norm_pair: shapes differ {tuple(x.shape)} vs {tuple(res.shape)}")
+    p = float(p_drop) if training else 0.0
+    if p > 0.0 and seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return _AddLayerNorm.apply(x, res, gamma, beta, float(eps), p, int(seed or 0))
+
+
 class _RMSNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, eps):
@@ -476,6 +542,31 @@ def adamw_step_(param, master, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
                                 eps, weight_decay, step, grad_scale, dtype_code(param), stream_ptr())
 
 
+# ------------------------------------------------------------------------------------------ frozen fc1 + ReLU
+class _FrozenLinearReLU(torch.autograd.Function):
+    """relu(x W^T + b) for a FROZEN weight: the library GEMM with its ReLU epilogue (no separate clamp pass, no
+    pre-activation kept), backward = mask by the saved output then ONE dgrad GEMM.  (frozen OPT fc1, reference :352-353)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1])
+        y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False)
+        ctx.save_for_backward(y, weight)
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, weight = ctx.saved_tensors
+        g = torch.ops.aten.threshold_backward(dy.reshape(y.shape), y, 0)
+        return (g @ weight).view(*dy.shape[:-1], weight.shape[1]), None, None
+
+
+def frozen_linear_relu(x, weight, bias):
+    if weight.requires_grad or bias is None or bias.requires_grad:
+        raise ValueError("frozen_linear_relu: weight and bias must be frozen (requires_grad=False)")
+    return _FrozenLinearReLU.apply(x, weight, bias)
+
+
 # ------------------------------------------------------------------------------------------ frozen encoders (forward only)
 ACT_CODES = {"relu": 1, "gelu": 2, "quick_gelu": 3, "gelu_new": 4, "gelu_pytorch_tanh": 4, "gelu_fast": 4}
 
@@ -514,8 +605,8 @@ def add_layer_norm(x, res, gamma, beta, eps, return_sum=False):
     s = torch.empty_like(x2) if return_sum else None
     g, b = gamma.to(x.dtype).contiguous(), beta.to(x.dtype).contiguous()
     if x2.shape[0]:
-        _lib.call("mmgl_add_layernorm_fwd", dict(bytes=(4.0 if return_sum else 3.0) * x2.numel() * x2.element_size()), ptr(x2), ptr(r2), ptr(g), ptr(b), ptr(s), ptr(y), x2.shape[0], cols, float(eps),
-                  dtype_code(x2), stream_ptr())
+        _lib.call("mmgl_add_layernorm_fwd", dict(bytes=(4.0 if return_sum else 3.0) * x2.numel() * x2.element_size()), ptr(x2), ptr(r2), ptr(g), ptr(b), ptr(s), ptr(y), None, None, x2.shape[0], cols, float(eps),
+                  0.0, 0, dtype_code(x2), stream_ptr())
     return (s.view(x.shape), y.view(x.shape)) if return_sum else y.view(x.shape)
 
 

@@ -40,6 +40,85 @@ def test_layernorm(rows, cols, dtype):
     assert_close(bd.grad.float(), br.grad, t, "dbeta")
 
 
+@pytest.mark.parametrize("rows,cols", [(37, 64), (640, 2048), (9, 1000)])
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("use_sum,affine_grad", [(True, True), (True, False), (False, False)])
+def test_add_layer_norm_pair(rows, cols, dtype, use_sum, affine_grad):
+    """(s, y) = (x + r, LN(x + r)) with both outputs feeding the loss: dx = dr = LN'(dy) + ds from one backward kernel."""
+    from mmgl_amd import ops
+    g = torch.Generator().manual_seed(rows * 3 + cols)
+    x, r = torch.randn(rows, cols, generator=g), torch.randn(rows, cols, generator=g) * 2
+    gamma, beta = torch.randn(cols, generator=g) * 0.2 + 1, torch.randn(cols, generator=g) * 0.1
+    w1, w2 = torch.randn(rows, cols, generator=g), torch.randn(rows, cols, generator=g)
+    xd, rd = dev(x, dtype), dev(r, dtype)
+    gd, bd = (dev(gamma, dtype), dev(beta, dtype)) if affine_grad else (gamma.to(dtype).cuda(), beta.to(dtype).cuda())
+    s, y = ops.add_layer_norm_pair(xd, rd, gd, bd, 1e-5)
+    loss = (y * w1.to(dtype).cuda()).sum() + ((s * w2.to(dtype).cuda()).sum() if use_sum else 0)
+    loss.backward()
+    xr, rr, gr, br = (t.detach().float().cpu().requires_grad_() for t in (xd, rd, gd, bd))
+    sr = (xr + rr).to(dtype).float() if dtype != torch.float32 else xr + rr
+    sr = xr + rr + (sr - (xr + rr)).detach()          # the rounded sum, gradient of the plain sum
+    yr = F.layer_norm(sr, (cols,), gr, br, 1e-5)
+    lr = (yr * w1.to(dtype).float()).sum() + ((sr * w2.to(dtype).float()).sum() if use_sum else 0)
+    lr.backward()
+    t = tol(dtype)
+    assert torch.equal(s, (xd + rd).detach())
+    assert_close(y.float(), yr, t, "y")
+    assert_close(xd.grad.float(), xr.grad, t, "dx")
+    assert torch.equal(xd.grad, rd.grad)
+    if affine_grad:
+        assert_close(gd.grad.float(), gr.grad, t, "dgamma")
+        assert_close(bd.grad.float(), br.grad, t, "dbeta")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_add_layer_norm_pair_dropout_matches_unfused(dtype):
+    """With dropout the fused pair must reproduce gated_residual(seed) -> layer_norm exactly in forward (same counter
+    hash, same rounding points) and within tolerance in backward."""
+    from mmgl_amd import ops
+    g = torch.Generator().manual_seed(11)
+    rows, cols, p, seed = 300, 2048, 0.3, 987654321
+    x, r = torch.randn(rows, cols, generator=g), torch.randn(rows, cols, generator=g)
+    gamma, beta = (torch.randn(cols, generator=g) * 0.2 + 1).to(dtype).cuda(), (torch.randn(cols, generator=g) * 0.1).to(dtype).cuda()
+    w1, w2 = torch.randn(rows, cols, generator=g).to(dtype).cuda(), torch.randn(rows, cols, generator=g).to(dtype).cuda()
+    xa, ra = dev(x, dtype), dev(r, dtype)
+    s, y = ops.add_layer_norm_pair(xa, ra, gamma, beta, 1e-5, p, True, seed=seed)
+    ((y * w1).sum() + (s * w2).sum()).backward()
+    xb, rb = dev(x, dtype), dev(r, dtype)
+    s2 = ops.gated_residual(rb, xb, None, p, True, seed=seed)
+    y2 = ops.layer_norm(s2, gamma, beta, 1e-5)
+    ((y2 * w1).sum() + (s2 * w2).sum()).backward()
+    assert torch.equal(s, s2) and torch.equal(y, y2)
+    dropped = (s.detach() == ra.detach()).float().mean().item()
+    assert abs(dropped - p) < 0.02
+    t = tol(dtype)
+    assert_close(xa.grad.float(), xb.grad.float(), t, "dx")
+    assert_close(ra.grad.float(), rb.grad.float(), t, "dres")
+    drop = s.detach() == ra.detach()                 # dropped elements pass the residual through unchanged
+    assert bool((xa.grad[drop] == 0).all()) and bool((xb.grad[drop] == 0).all())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_frozen_linear_relu(dtype):
+    from mmgl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = dev(torch.randn(3, 50, 64, generator=g), dtype)
+    W = (torch.randn(96, 64, generator=g) * 0.2).to(dtype).cuda()
+    b = (torch.randn(96, generator=g) * 0.2).to(dtype).cuda()
+    w = torch.randn(3, 50, 96, generator=g).to(dtype).cuda()
+    y = ops.frozen_linear_relu(x, W, b)
+    (y * w).sum().backward()
+    xr = x.detach().float().cpu().requires_grad_()
+    yr = F.relu(F.linear(xr, W.float().cpu(), b.float().cpu()))
+    keep = (y.detach().float().cpu() > 0) == (yr > 0)                    # rounding may flip a sign at pre-activation ~ 0
+    (yr * w.float().cpu() * keep).sum().backward()
+    t = tol(dtype, bf=3e-2)
+    assert_close(y.float(), yr, t, "y")
+    assert_close(x.grad.float(), xr.grad, t, "dx")
+    with pytest.raises(ValueError):
+        ops.frozen_linear_relu(x, W.clone().requires_grad_(), b)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layernorm_frozen_affine(dtype):
     from mmgl_amd import ops
