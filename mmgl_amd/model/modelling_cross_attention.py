@@ -183,7 +183,7 @@ class MPTAttention(nn.Module):
                 raise ValueError("layer_head_mask / output_attentions / attention dropout need the unfused self-attention path")
             fused = self._frozen_qkv()
             if fused is not None:            # frozen layer: one QKV GEMM forward, one dgrad GEMM backward, no gradient adds
-                o = ops.selfattn_core_fused(F.linear(hidden_states, *fused), attention_mask, H)
+                o = ops.selfattn_core_fused(ops.frozen_linear(hidden_states, *fused), attention_mask, H)
                 return self.out_proj(o), None, None
             q = self.q_proj(hidden_states) * self.scaling
             o = ops.selfattn_core(q, self.k_proj(hidden_states), self.v_proj(hidden_states), attention_mask, H)
@@ -317,9 +317,9 @@ class MPTDecoderLayer(nn.Module):
                 h = self._ln(ln1, h)
             x = self._ln(ln2, h) if pre else h
         residual = h
-        if (self.activation_name == "relu" and x.is_cuda and not self.fc1.weight.requires_grad and self.fc1.bias is not None
-                and not self.fc1.bias.requires_grad):
-            x = self.fc2(ops.frozen_linear_relu(x, self.fc1.weight, self.fc1.bias))
+        frozen = x.is_cuda and not any(p.requires_grad for p in (*self.fc1.parameters(), *self.fc2.parameters()))
+        if frozen and self.activation_name == "relu" and self.fc1.bias is not None:
+            x = ops.frozen_linear(ops.frozen_linear(x, self.fc1.weight, self.fc1.bias, relu=True), self.fc2.weight, self.fc2.bias)
         else:
             x = self.fc2(self.activation_fn(self.fc1(x)))
         if fuse and pre and defer_residual:

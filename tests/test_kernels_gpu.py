@@ -94,8 +94,9 @@ def test_add_layer_norm_pair_dropout_matches_unfused(dtype):
     t = tol(dtype)
     assert_close(xa.grad.float(), xb.grad.float(), t, "dx")
     assert_close(ra.grad.float(), rb.grad.float(), t, "dres")
-    drop = s.detach() == ra.detach()                 # dropped elements pass the residual through unchanged
-    assert bool((xa.grad[drop] == 0).all()) and bool((xb.grad[drop] == 0).all())
+    if dtype == torch.float32:                       # dropped elements pass the residual through unchanged (in bf16 a small
+        drop = s.detach() == ra.detach()             # kept x can round away too, so the forward cannot identify them)
+        assert bool((xa.grad[drop] == 0).all()) and bool((xb.grad[drop] == 0).all())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -117,6 +118,12 @@ def test_frozen_linear_relu(dtype):
     assert_close(x.grad.float(), xr.grad, t, "dx")
     with pytest.raises(ValueError):
         ops.frozen_linear_relu(x, W.clone().requires_grad_(), b)
+    for cache_wt in (True, False):                        # plain frozen linear, both dgrad layouts
+        x2 = x.detach().clone().requires_grad_()
+        (ops.frozen_linear(x2, W, b, cache_wt=cache_wt) * w).sum().backward()
+        xr2 = x.detach().float().cpu().requires_grad_()
+        (F.linear(xr2, W.float().cpu(), b.float().cpu()) * w.float().cpu()).sum().backward()
+        assert_close(x2.grad.float(), xr2.grad, t, f"dx cache_wt={cache_wt}")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
