@@ -652,6 +652,166 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
     }
 }
 
+// ============================================================================================ backward: dK, dV (bf16, D <= 64)
+// One WAVE = one workgroup = (b, h, 64-key group): twice the keys per wave of the generic kernel above, no parity split.
+// The generic kernel moves 16 KiB through LDS (tile write + tr16 reads) per 32 MFMAs per wave -- with 4 waves per CU that
+// is the whole 128 B/clk LDS port; here the same 16 KiB feed 64 MFMAs.  K / V fragments are loaded once, straight from
+// global memory into registers (they are the B operands of S = Q K^T and dP = dO V^T); Q / dO row fragments, LSE and
+// delta are requested one tile ahead (vmcnt is a single in-order counter: a load consumed in the iteration that issues it
+// would also wait for the prefetches queued before it) into a second register set -- the loop is unrolled by two and the
+// sets swap roles, so nothing is copied -- and dropped into the wave-private tile for the transposed (tr16) reads of
+// dV += P^T dO, dK += dS^T Q.  Branch-free body: bounds by buffer descriptors, masks by selects feeding exp2(-inf) = 0.
+// No barrier, no cross-wave reduction: every dK / dV element is produced by one wave.
+template <int D>
+__global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ q,
+                                                                const bf16* __restrict__ k, const bf16* __restrict__ v,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                const uint8_t* __restrict__ valid, bf16* __restrict__ dk,
+                                                                bf16* __restrict__ dv, int B, int H, int T_, int nkb, int ldq, int ldg) {
+    typedef bf16 T;
+    typedef XC<T, D, 4> C;                         // 64 keys = 4 blocks
+    typedef bf16x8 v8;
+    constexpr int LDT = C::DPAD + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Qt = (T*)smem;                              // [32][LDT]
+    T* Gt = Qt + 32 * LDT;
+    const int lane = threadIdx.x;
+    const int x = lane & 15, g = lane >> 4;
+
+    const int vid = xcd_remap(blockIdx.x, B * H * nkb);
+    const int bh = vid / nkb, kblk = vid % nkb;                 // low key groups (most query tiles) first
+    const int b = bh / H, h = bh % H;
+    const size_t HD = (size_t)H * D;
+    const int s0 = kblk * 64;
+    const uint32_t rbq = (uint32_t)(ldq * sizeof(T)), rbo = (uint32_t)(HD * sizeof(T));
+    const uint32_t slabq = (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T)), slabo = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * ldq + h * D, slabq);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * T_ * ldq + h * D, slabq);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * T_ * ldq + h * D, slabq);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(dout + (size_t)b * T_ * HD + h * D, slabo);
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(delta + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
+
+    v8 kf[4][C::NDC], vf[4][C::NDC];
+    float kbias[4];                                // 0 for a real, valid key of this lane's column; -inf otherwise
+#pragma unroll
+    for (int sbl = 0; sbl < 4; ++sbl) {
+        const int s = s0 + sbl * 16 + x;
+        kbias[sbl] = (s < T_ && valid[(size_t)b * T_ + min(s, T_ - 1)] != 0) ? 0.f : -INFINITY;
+#pragma unroll
+        for (int dc = 0; dc < C::NDC; ++dc) {
+            kf[sbl][dc] = buf_load8<T>(rk, row_off<T, C>(s, rbq, dc * 32 + g * 8));
+            vf[sbl][dc] = buf_load8<T>(rv, row_off<T, C>(s, rbq, dc * 32 + g * 8));
+        }
+    }
+    f32x4 dva[C::NDB][4], dka[C::NDB][4];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int sbl = 0; sbl < 4; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
+
+    auto request = [&](int tbase, v8 (&qn)[2][C::NDC], v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc) {
+                qn[tb][dc] = buf_load8<T>(rq, row_off<T, C>(tbase + tb * 16 + x, rbq, dc * 32 + g * 8));
+                gn[tb][dc] = buf_load8<T>(rg, row_off<T, C>(tbase + tb * 16 + x, rbo, dc * 32 + g * 8));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t o = (uint32_t)(tbase + tb * 16 + g * 4 + r) * 4u;
+                ln[tb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
+                dn[tb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, o, 0, 0));
+            }
+        }
+    };
+
+    auto step = [&](int t0, v8 (&qa)[2][C::NDC], v8 (&ga)[2][C::NDC], float (&la)[2][4], float (&da)[2][4], v8 (&qn)[2][C::NDC],
+                    v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
+        request(t0 + 32, qn, gn, ln, dn);
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc) {
+                *(v8*)(Qt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = qa[tb][dc];
+                *(v8*)(Gt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = ga[tb][dc];
+            }
+        const bool diag = t0 < s0 + 63;                         // some (row, key) pair with key > row (wave-uniform)
+        float lt[2][4];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lt[tb][r] = (t0 + tb * 16 + g * 4 + r < T_) ? la[tb][r] * LOG2E : INFINITY;   // row past T: p = 0
+        v8 pB[4], dsB[4];
+#pragma unroll
+        for (int sbl = 0; sbl < 4; ++sbl) {
+            f32x4 pr[2], dsr[2];
+            const int s = s0 + sbl * 16 + x;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                f32x4 sa = vzero<f32x4>(), pa = vzero<f32x4>();
+#pragma unroll
+                for (int dc = 0; dc < C::NDC; ++dc) {
+                    mma16(sa, qa[tb][dc], kf[sbl][dc]);
+                    mma16(pa, ga[tb][dc], vf[sbl][dc]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float e = fmaf(sa[r], LOG2E, kbias[sbl] - lt[tb][r]);
+                    if (diag) e = (s <= t0 + tb * 16 + g * 4 + r) ? e : -INFINITY;
+                    const float p = __builtin_amdgcn_exp2f(e);
+                    pr[tb][r] = p;
+                    dsr[tb][r] = p * (pa[r] - da[tb][r]);
+                }
+            }
+            pB[sbl] = pack8<T>(pr[0], pr[1]);
+            dsB[sbl] = pack8<T>(dsr[0], dsr[1]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) {
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+            const bf16* pg = Gt + (4 * g + (x >> 2)) * LDT + db * 16 + (x & 3) * 4;
+            const bf16* pq = Qt + (4 * g + (x >> 2)) * LDT + db * 16 + (x & 3) * 4;
+            const bf16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pg);
+            const bf16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pg + 16 * LDT));
+            const bf16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pq);
+            const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pq + 16 * LDT));
+            const v8 gT = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+            const v8 qT = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+            for (int sbl = 0; sbl < 4; ++sbl) {
+                mma16(dva[db][sbl], gT, pB[sbl]);
+                mma16(dka[db][sbl], qT, dsB[sbl]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    v8 qA[2][C::NDC], gA[2][C::NDC], qB[2][C::NDC], gB[2][C::NDC];
+    float lA[2][4], dA[2][4], lB[2][4], dB[2][4];
+    request(s0, qA, gA, lA, dA);
+    for (int t0 = s0; t0 < T_; t0 += 64) {
+        step(t0, qA, gA, lA, dA, qB, gB, lB, dB);
+        if (t0 + 32 < T_) step(t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
+    }
+#pragma unroll
+    for (int sbl = 0; sbl < 4; ++sbl) {
+        const int s = s0 + sbl * 16 + x;
+        if (s < T_) {
+            const size_t off = ((size_t)b * T_ + s) * ldg + h * D + g * 4;
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db) {
+                store4<T>(dk + off + db * 16, dka[db][sbl]);
+                store4<T>(dv + off + db * 16, dva[db][sbl]);
+            }
+        }
+    }
+}
+
 // ============================================================================================ host
 template <typename K> int set_lds_sa(K kern, size_t bytes) {
     if (bytes > 160 * 1024) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "selfattn: needs %zu B of LDS (> 160 KiB)", bytes);
@@ -708,6 +868,19 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
             if (par == 2 && red > tiles) tiles = red;
             return sizeof(T) * 4 * C::ROWIMG + tiles;
         };
+        static const int use64 = [] { const char* e = getenv("MMGL_SELFATTN_DKV64"); return e ? atoi(e) : 1; }();
+        if constexpr (sizeof(T) == 2 && D <= 64) {
+            if (use64) {
+                typedef XC<bf16, D, 4> C4;
+                const int nkb64 = cdiv(T_, 64);
+                const size_t lds64 = sizeof(bf16) * 2 * 32 * (C4::DPAD + 16);
+                hipLaunchKernelGGL((selfattn_bwd_dkv64_kernel<D>), dim3(B * H * nkb64), dim3(64), lds64, st, (const bf16*)dout,
+                                   (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, (bf16*)dk, (bf16*)dv, B, H, T_,
+                                   nkb64, ldq, ldg);
+                MMGL_CHECK_LAUNCH("selfattn_bwd_dkv64");
+                return MMGL_OK;
+            }
+        }
         if (lds_for(2) <= 160 * 1024) {
             auto kern = selfattn_bwd_dkv_kernel<T, D, 2>;
             int rc = set_lds_sa(kern, lds_for(2));

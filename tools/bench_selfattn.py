@@ -27,8 +27,8 @@ def run(B, H=32, T=640, D=64, dtype=torch.bfloat16, iters=50):
     ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
     code = _lib.dtype_code(q)
     st = stream_ptr()
-    fwd = lambda: L.mmgl_selfattn_fwd(ptr(q), ptr(k), ptr(v), ptr(valid), ptr(out), ptr(lse), B, H, T, D, code, st)
-    bwd = lambda: L.mmgl_selfattn_bwd(ptr(w), ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(valid), ptr(dq), ptr(dk), ptr(dv), ptr(ws), nws, B, H, T, D, code, st)
+    fwd = lambda: L.mmgl_selfattn_fwd(ptr(q), ptr(k), ptr(v), ptr(valid), ptr(out), ptr(lse), B, H, T, D, 0, code, st)
+    bwd = lambda: L.mmgl_selfattn_bwd(ptr(w), ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(valid), ptr(dq), ptr(dk), ptr(dv), ptr(ws), nws, B, H, T, D, 0, 0, code, st)
     for _ in range(3):
         assert fwd() == 0 and bwd() == 0
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
