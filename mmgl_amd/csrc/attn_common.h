@@ -165,7 +165,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
-#define OOB 0xFFFFFFF0u          // byte offset past any descriptor range: loads return 0, stores are dropped
+#define OOB 0x80000000u          // byte offset past any descriptor range (< 2 GiB), with room for +offsets without wrapping: loads return 0, stores are dropped
 
 // Hardware-bounds-checked buffer access: rows past T (and the zero-padded channels of D = 16) need no branches, so the
 // compiler sees every VMEM op of the loop and can wait with exact vmcnt counts (loads of the NEXT tile stay in flight

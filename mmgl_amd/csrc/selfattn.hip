@@ -43,6 +43,20 @@ template <typename T, typename C, bool K_ROWMAJOR, bool V_ROWMAJOR> struct TileS
         }
         vb = (threadIdx.x < KT && s0 + (int)threadIdx.x < T_) ? (valid_row ? valid_row[s0 + threadIdx.x] : (uint8_t)1) : 0;
     }
+    // branch-free form: rows past the end of the sequence / padding channels fall outside the descriptor and read as 0
+    __device__ __forceinline__ void loadb(__amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv, uint32_t row_bytes,
+                                          const uint8_t* valid_row, int s0, int T_) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int id = threadIdx.x + i * 256, s = id / C::CPR, c = id % C::CPR;
+            const uint32_t off = row_off<T, C>(s0 + s, row_bytes, c * 8);
+            kr[i] = buf_load8<T>(rk, off);
+            vr[i] = buf_load8<T>(rv, off);
+        }
+        const int sv = s0 + (int)(threadIdx.x & (KT - 1));
+        const uint8_t vv = valid_row ? valid_row[min(sv, T_ - 1)] : (uint8_t)1;
+        vb = (sv < T_) ? vv : (uint8_t)0;
+    }
     __device__ __forceinline__ void store(T* Kimg, T* Vimg, uint8_t* vld) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -66,9 +80,11 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
     typedef typename Elem<T>::v8 v8;
     constexpr int TILE = 16 * C::QT, QB = 4 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Kf = (T*)smem;
-    T* Vi = Kf + C::ROWIMG;
-    uint8_t* vld = (uint8_t*)(Vi + (C::TIMG ? C::RMIMG : C::ROWIMG));
+    constexpr int VIMG = C::TIMG ? C::RMIMG : C::ROWIMG;
+    constexpr int BUFB = (int)(sizeof(T) * (C::ROWIMG + VIMG)) + KT;             // one K/V tile buffer (multiple of 16 B)
+    auto Kimg = [&](int i) { return (T*)(smem + i * BUFB); };
+    auto Vimg = [&](int i) { return (T*)(smem + i * BUFB) + C::ROWIMG; };
+    auto Vld = [&](int i) { return (uint8_t*)(smem + i * BUFB) + sizeof(T) * (C::ROWIMG + VIMG); };
 
     const int vid = xcd_remap(blockIdx.x, B * H * nqb);
     const int bh = vid / nqb, qblk = nqb - 1 - vid % nqb;        // longest (most key tiles) first
@@ -85,8 +101,9 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * ldq + h * D, (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T)));
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)b * T_ * HD + h * D, slab);
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
-    const T* kb = k + (size_t)b * T_ * ldq + h * D;
-    const T* vb = v + (size_t)b * T_ * ldq + h * D;
+    const uint32_t slabk = (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * T_ * ldq + h * D, slabk);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * T_ * ldq + h * D, slabk);
 
     v8 qf[C::QT][C::NDC];
 #pragma unroll
@@ -105,12 +122,17 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
     }
 
     TileStage<T, C, false, C::TIMG> stg;
-    stg.load(kb, vb, valid + (size_t)b * T_, (size_t)ldq, 0, T_);
-    stg.store(Kf, Vi, vld);
+    stg.loadb(rk, rv, rbq, valid + (size_t)b * T_, 0, T_);
+    stg.store(Kimg(0), Vimg(0), Vld(0));
     __syncthreads();
+    // two LDS tile buffers, ONE barrier per key tile: tile j+1 is written into the other buffer after this wave's MFMAs of
+    // tile j; the barrier at the end of iteration j both publishes it and proves every wave is done reading tile j-1's buffer.
     for (int j = 0; j < nkt; ++j) {
         const int s0 = j * KT;
-        if (j + 1 < nkt) stg.load(kb, vb, valid + (size_t)b * T_, (size_t)ldq, s0 + KT, T_);
+        const T* Kf = Kimg(j & 1);
+        const T* Vi = Vimg(j & 1);
+        const uint8_t* vld = Vld(j & 1);
+        if (j + 1 < nkt) stg.loadb(rk, rv, rbq, valid + (size_t)b * T_, s0 + KT, T_);
         if (s0 <= t0 + TILE - 1) {                            // else: tile entirely above this wave's diagonal (wave-uniform)
 
         f32x4 bias[4];
@@ -174,8 +196,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
                 for (int qt = 0; qt < C::QT; ++qt) mma16(oacc[qt][db], vt, pf[qt][ks]);
             }
         }
-        __syncthreads();                                      // every wave is done reading tile j
-        if (j + 1 < nkt) stg.store(Kf, Vi, vld);
+        if (j + 1 < nkt) stg.store(Kimg((j + 1) & 1), Vimg((j + 1) & 1), Vld((j + 1) & 1));
         __syncthreads();
     }
 #pragma unroll
@@ -204,9 +225,11 @@ __global__ __launch_bounds__(256) void encattn_fwd_kernel(const T* __restrict__ 
     typedef typename Elem<T>::v8 v8;
     constexpr int TILE = 16 * C::QT, QB = 4 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Kf = (T*)smem;
-    T* Vi = Kf + C::ROWIMG;
-    uint8_t* vld = (uint8_t*)(Vi + (C::TIMG ? C::RMIMG : C::ROWIMG));
+    constexpr int VIMG = C::TIMG ? C::RMIMG : C::ROWIMG;
+    constexpr int BUFB = (int)(sizeof(T) * (C::ROWIMG + VIMG)) + KT;
+    auto Kimg = [&](int i) { return (T*)(smem + i * BUFB); };
+    auto Vimg = [&](int i) { return (T*)(smem + i * BUFB) + C::ROWIMG; };
+    auto Vld = [&](int i) { return (uint8_t*)(smem + i * BUFB) + sizeof(T) * (C::ROWIMG + VIMG); };
 
     const int vid = xcd_remap(blockIdx.x, nseq * H * nqb);
     const int sh = vid / nqb, qblk = vid % nqb;
@@ -222,8 +245,9 @@ __global__ __launch_bounds__(256) void encattn_fwd_kernel(const T* __restrict__ 
     const uint32_t rb_in = (uint32_t)(ld_in * sizeof(T)), rb_out = (uint32_t)(ld_out * sizeof(T));
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)start * ld_in + h * D, (uint32_t)(((size_t)(qlen - 1) * ld_in + D) * sizeof(T)));
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)start * ld_out + h * D, (uint32_t)(((size_t)(qlen - 1) * ld_out + D) * sizeof(T)));
-    const T* kb = k + (size_t)start * ld_in + h * D;
-    const T* vb = v + (size_t)start * ld_in + h * D;
+    const uint32_t slabk = (uint32_t)(((size_t)(len - 1) * ld_in + D) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)start * ld_in + h * D, slabk);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)start * ld_in + h * D, slabk);
 
     v8 qf[C::QT][C::NDC];
 #pragma unroll
@@ -242,11 +266,14 @@ __global__ __launch_bounds__(256) void encattn_fwd_kernel(const T* __restrict__ 
     }
 
     TileStage<T, C, false, C::TIMG> stg;
-    stg.load(kb, vb, nullptr, (size_t)ld_in, 0, len);
-    stg.store(Kf, Vi, vld);
+    stg.loadb(rk, rv, rb_in, nullptr, 0, len);
+    stg.store(Kimg(0), Vimg(0), Vld(0));
     __syncthreads();
-    for (int j = 0; j < nkt; ++j) {
-        if (j + 1 < nkt) stg.load(kb, vb, nullptr, (size_t)ld_in, (j + 1) * KT, len);
+    for (int j = 0; j < nkt; ++j) {                           // double-buffered tiles, one barrier each (see selfattn_fwd_kernel)
+        const T* Kf = Kimg(j & 1);
+        const T* Vi = Vimg(j & 1);
+        const uint8_t* vld = Vld(j & 1);
+        if (j + 1 < nkt) stg.loadb(rk, rv, rb_in, nullptr, (j + 1) * KT, len);
         f32x4 bias[4];
         tile_bias<C>(vld, g, bias);                           // -inf for the keys past the end of the sequence
         f32x4 sacc[C::QT][4];
@@ -298,8 +325,7 @@ __global__ __launch_bounds__(256) void encattn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
                 for (int qt = 0; qt < C::QT; ++qt) mma16(oacc[qt][db], vt, pf[qt][ks]);
             }
-        __syncthreads();
-        if (j + 1 < nkt) stg.store(Kf, Vi, vld);
+        if (j + 1 < nkt) stg.store(Kimg((j + 1) & 1), Vimg((j + 1) & 1), Vld((j + 1) & 1));
         __syncthreads();
     }
 #pragma unroll
@@ -349,9 +375,11 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
     typedef typename Elem<T>::v8 v8;
     constexpr int TILE = 16 * C::QT, QB = 4 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Ki = (T*)smem;                                          // row-major (bf16) / row image (f32)
-    T* Vf = Ki + (C::TIMG ? C::RMIMG : C::ROWIMG);
-    uint8_t* vld = (uint8_t*)(Vf + C::ROWIMG);
+    constexpr int KIMG = C::TIMG ? C::RMIMG : C::ROWIMG;      // K: row-major (bf16) / row image (f32)
+    constexpr int BUFB = (int)(sizeof(T) * (KIMG + C::ROWIMG)) + KT;
+    auto Kimg = [&](int i) { return (T*)(smem + i * BUFB); };
+    auto Vimg = [&](int i) { return (T*)(smem + i * BUFB) + KIMG; };
+    auto Vld = [&](int i) { return (uint8_t*)(smem + i * BUFB) + sizeof(T) * (KIMG + C::ROWIMG); };
 
     const int vid = xcd_remap(blockIdx.x, B * H * nqb);
     const int bh = vid / nqb, qblk = nqb - 1 - vid % nqb;
@@ -367,8 +395,9 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * ldq + h * D, (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T)));
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(dout + (size_t)b * T_ * HD + h * D, slab);
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(dq + (size_t)b * T_ * ldg + h * D, (uint32_t)(((size_t)(T_ - 1) * ldg + D) * sizeof(T)));
-    const T* kb = k + (size_t)b * T_ * ldq + h * D;
-    const T* vb = v + (size_t)b * T_ * ldq + h * D;
+    const uint32_t slabk = (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * T_ * ldq + h * D, slabk);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * T_ * ldq + h * D, slabk);
 
     v8 qf[C::QT][C::NDC], gf[C::QT][C::NDC];
     float lse2[C::QT], dlt[C::QT];
@@ -390,12 +419,15 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
         for (int db = 0; db < C::NDB; ++db) acc[qt][db] = vzero<f32x4>();
 
     TileStage<T, C, C::TIMG, false> stg;
-    stg.load(kb, vb, valid + (size_t)b * T_, (size_t)ldq, 0, T_);
-    stg.store(Ki, Vf, vld);
+    stg.loadb(rk, rv, rbq, valid + (size_t)b * T_, 0, T_);
+    stg.store(Kimg(0), Vimg(0), Vld(0));
     __syncthreads();
-    for (int j = 0; j < nkt; ++j) {
+    for (int j = 0; j < nkt; ++j) {                           // double-buffered tiles, one barrier each (see selfattn_fwd_kernel)
         const int s0 = j * KT;
-        if (j + 1 < nkt) stg.load(kb, vb, valid + (size_t)b * T_, (size_t)ldq, s0 + KT, T_);
+        const T* Ki = Kimg(j & 1);
+        const T* Vf = Vimg(j & 1);
+        const uint8_t* vld = Vld(j & 1);
+        if (j + 1 < nkt) stg.loadb(rk, rv, rbq, valid + (size_t)b * T_, s0 + KT, T_);
         if (s0 <= t0 + TILE - 1) {
 
         f32x4 bias[4];
@@ -448,8 +480,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
                 for (int qt = 0; qt < C::QT; ++qt) mma16(acc[qt][db], kt, dsf[qt][ks]);
             }
         }
-        __syncthreads();
-        if (j + 1 < nkt) stg.store(Ki, Vf, vld);
+        if (j + 1 < nkt) stg.store(Kimg((j + 1) & 1), Vimg((j + 1) & 1), Vld((j + 1) & 1));
         __syncthreads();
     }
 #pragma unroll
@@ -827,7 +858,7 @@ int sa_fwd(const void* q, const void* k, const void* v, const uint8_t* valid, vo
            int ldq, hipStream_t st) {
     typedef SC<T, D> C;
     const int QB = 4 * 16 * C::QT, nqb = cdiv(T_, QB);
-    const size_t lds = sizeof(T) * (C::ROWIMG + (C::TIMG ? C::RMIMG : C::ROWIMG)) + KT;
+    const size_t lds = 2 * (sizeof(T) * (C::ROWIMG + (C::TIMG ? C::RMIMG : C::ROWIMG)) + KT);
     auto kern = selfattn_fwd_kernel<T, D>;
     int rc = set_lds_sa(kern, lds);
     if (rc) return rc;
@@ -850,7 +881,7 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
     {
         typedef XC<T, D, 4, 2> C;
         const int QB = 4 * 16 * C::QT, nqb = cdiv(T_, QB);
-        const size_t lds = sizeof(T) * ((C::TIMG ? C::RMIMG : C::ROWIMG) + C::ROWIMG) + KT;
+        const size_t lds = 2 * (sizeof(T) * ((C::TIMG ? C::RMIMG : C::ROWIMG) + C::ROWIMG) + KT);
         auto kern = selfattn_bwd_dq_kernel<T, D>;
         int rc = set_lds_sa(kern, lds);
         if (rc) return rc;
@@ -905,7 +936,7 @@ int enc_fwd(const void* q, const void* k, const void* v, const int* cu, void* ou
     typedef SC<T, D> C;
     const int QB = 4 * 16 * C::QT;
     const int nqb = cdiv(max_len < q_rows ? max_len : q_rows, QB);
-    const size_t lds = sizeof(T) * (C::ROWIMG + (C::TIMG ? C::RMIMG : C::ROWIMG)) + KT;
+    const size_t lds = 2 * (sizeof(T) * (C::ROWIMG + (C::TIMG ? C::RMIMG : C::ROWIMG)) + KT);
     auto kern = encattn_fwd_kernel<T, D>;
     int rc = set_lds_sa(kern, lds);
     if (rc) return rc;

@@ -5,6 +5,7 @@ entry point on torch's current stream and returns fresh tensors owned by autogra
 """
 import math
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -553,15 +554,19 @@ _WT_CACHE = {}
 
 
 def _transposed(weight):
-    """W^T as a contiguous tensor, cached per parameter storage / version (frozen weights: built once)."""
-    key = weight.data_ptr()
-    tag = (weight._version, weight.dtype, tuple(weight.shape))
+    """W^T as a contiguous tensor, cached per weight OBJECT (weakref-checked: an id or an address can be reused by a later
+    tensor) and rebuilt when its storage / version / dtype changes (load_state_dict, .bfloat16(), flattening)."""
+    key = id(weight)
+    tag = (weight.data_ptr(), weight._version, weight.dtype, tuple(weight.shape))
     hit = _WT_CACHE.get(key)
-    if hit is None or hit[0] != tag:
+    if hit is None or hit[0]() is not weight or hit[1] != tag:
+        if len(_WT_CACHE) > 4096:                             # drop entries of dead tensors
+            for k in [k for k, h in _WT_CACHE.items() if h[0]() is None]:
+                del _WT_CACHE[k]
         with torch.no_grad():
-            hit = (tag, weight.detach().t().contiguous())
+            hit = (weakref.ref(weight), tag, weight.detach().t().contiguous())
         _WT_CACHE[key] = hit
-    return hit[1]
+    return hit[2]
 
 
 class _FrozenLinear(torch.autograd.Function):
