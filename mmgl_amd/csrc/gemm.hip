@@ -175,6 +175,115 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ X, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Large-shape forward GEMM (bf16, K % 64 == 0): 256x256 block tile, 8 waves as 4 (W rows) x 2 (X rows), each wave
+// 64x128 = 4x8 MFMA tiles, one workgroup per CU (128 KiB of LDS: two K-tile buffers).  Against the 128x128 kernel above: a
+// wave reads 12 KiB of fragments per 32 MFMAs instead of 8 KiB per 16, a K tile keeps each SIMD in MFMAs for ~1000 cycles
+// per wave between barriers (two waves per SIMD cover each other's LDS waits), and the LDS-DMA of tile kt+1 is issued
+// a whole tile ahead.  Same XOR-swizzled 128-byte LDS rows, same epilogue.
+constexpr int BT = 256;
+constexpr int BIG_TILE_BYTES = BT * ROWB;              // 32 KiB per operand per buffer
+
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
+                                                            bf16* __restrict__ Y, const bf16* __restrict__ bias, int M, int N,
+                                                            int K, float scale, int accumulate, int tiles_m, int tiles_n) {
+    typedef bf16 T;
+    typedef GT<T> G;
+    typedef bf16x8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;                           // [2][BIG_TILE_BYTES]
+    char* sW = smem + 2 * BIG_TILE_BYTES;      // [2][BIG_TILE_BYTES]
+    const int vid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tn = vid / tiles_m, tm = vid % tiles_m;
+    const int m0 = tm * BT, n0 = tn * BT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = lane & 15, g = lane >> 4;
+    const int wn = wave >> 1, wm = wave & 1;           // wave tile: W rows wn*64 .. +63 (4 blocks), X rows wm*128 .. +127 (8 blocks)
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = vzero<f32x4>();
+
+    const int nk = K / G::BK;
+    auto glds_tile = [&](int kt, int buf) {
+        const int k0 = kt * G::BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rbase = (i * 8 + wave) * 8;
+            const int row = rbase + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const T* gx = X + (size_t)min(m0 + row, M - 1) * K + k0 + c * G::VN;
+            const T* gw = W + (size_t)min(n0 + row, N - 1) * K + k0 + c * G::VN;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gx,
+                                             (__attribute__((address_space(3))) void*)(sX + buf * BIG_TILE_BYTES + rbase * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,
+                                             (__attribute__((address_space(3))) void*)(sW + buf * BIG_TILE_BYTES + rbase * ROWB), 16, 0, 0);
+        }
+    };
+    glds_tile(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) glds_tile(kt + 1, buf ^ 1);
+        const char* tX = sX + buf * BIG_TILE_BYTES;
+        const char* tW = sW + buf * BIG_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < G::KSTEPS; ++ks) {
+            v8 fw[4], fx[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fw[i] = lds_frag<T>(tW, wn * 64 + i * 16 + x, ks, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fx[j] = lds_frag<T>(tX, wm * 128 + j * 16 + x, ks, g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mma16(acc[i][j], fw[i], fx[j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = m0 + wm * 128 + j * 16 + x;
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + g * 4;
+            if (n >= N) continue;
+            f32x4 v = acc[i][j];
+            if (bias) {
+                const bf16x4 bv = *(const bf16x4*)(bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
+            }
+            v *= scale;
+            if (ACT == MMGL_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            T* yp = Y + (size_t)m * N + n;
+            if (accumulate) {
+                const bf16x4 ov = *(const bf16x4*)yp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
+            }
+            *(bf16x4*)yp = __builtin_convertvector(v, bf16x4);
+        }
+    }
+}
+
+// shape test shared by launch_gemm and the backward planners: the 256x256 kernel needs whole 64-wide K tiles and enough
+// tiles to fill the chip twice (below that the 128x128 kernel's finer tiling wins)
+inline bool big_tile_shape(int M, int N, int K) { return K % 64 == 0 && (size_t)cdiv(M, 256) * cdiv(N, 256) >= 512; }
+
+inline int tune_gemm_big() {
+    static const int v = [] { const char* e = getenv("MMGL_GEMM_BIG"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 // out[C,R] = transpose(f(in[R,C])) with f = (* scale) and optional ReLU mask from yact[R,C] (> 0);
 // optional colsum[C] (+)= sum over R of f(in) (fp32 atomics are avoided: one block owns a full column strip).
 // 64x64 tiles through LDS; grid.x = column strips, block loops over all row tiles of its strip.
@@ -247,6 +356,22 @@ int launch_gemm(const T* X, const T* W, T* Y, const T* bias, int M, int N, int K
     MMGL_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: M,N,K must be positive (got %d,%d,%d)", M, N, K);
     if (K % VN || N % 4 || (X2 && K2 % VN))
         MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm: K (%d) must be a multiple of %d and N (%d) of 4", K, VN, N);
+    if constexpr (sizeof(T) == 2) {
+        // big-tile kernel when the shape fills the chip with 256x256 tiles (>= 2 tiles per CU keeps the tail small)
+        if (!X2 && tune_gemm_big() && big_tile_shape(M, N, K)) {
+            const int tm = cdiv(M, BT), tn = cdiv(N, BT);
+            const size_t ldsb = 4 * BIG_TILE_BYTES;
+            const void* kb = act == MMGL_ACT_RELU ? (const void*)gemm_nt256_kernel<MMGL_ACT_RELU> : (const void*)gemm_nt256_kernel<MMGL_ACT_NONE>;
+            hipError_t eb = hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            if (eb != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(eb));
+            if (act == MMGL_ACT_RELU)
+                hipLaunchKernelGGL((gemm_nt256_kernel<MMGL_ACT_RELU>), dim3(tm * tn), dim3(512), ldsb, st, X, W, Y, bias, M, N, K, scale, accumulate, tm, tn);
+            else
+                hipLaunchKernelGGL((gemm_nt256_kernel<MMGL_ACT_NONE>), dim3(tm * tn), dim3(512), ldsb, st, X, W, Y, bias, M, N, K, scale, accumulate, tm, tn);
+            MMGL_CHECK_LAUNCH("gemm_nt256");
+            return MMGL_OK;
+        }
+    }
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
     const size_t lds = 4 * TILE_BYTES;
     const bool glds = (K % GT<T>::BK == 0) && (!X2 || K2 % GT<T>::BK == 0) && tune_gemm_glds();
@@ -570,6 +695,11 @@ int launch_relu_mask(const T* dy, const T* y, T* out, size_t n, float scale, hip
     return MMGL_OK;
 }
 
+// bf16 backward workspace: [dyp M*N (only with an activation)] [bias column-sum partials] [W^T K*N (big-tile dgrad)]
+inline size_t bf16_wt_offset(int M, int N, int act) {
+    return (act ? align_up((size_t)M * N * 2, 256) : 0) + align_up((size_t)COLSUM_SPLITS * N * sizeof(float), 256);
+}
+
 template <typename T>
 int linear_dgrad(const T* dy, const T* y, const T* W, T* dx, char* ws, int M, int N, int K, int act, float scale, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {     // bf16: no transposes; dyp = dy*scale*(y>0) is materialised ONCE (masking inside the
@@ -581,6 +711,12 @@ int linear_dgrad(const T* dy, const T* y, const T* W, T* dx, char* ws, int M, in
             if (rc) return rc;
             a = (const bf16*)ws;
             sc = 1.f;
+        }
+        if (tune_gemm_big() && big_tile_shape(M, K, N)) {
+            T* Wt = (T*)(ws + bf16_wt_offset(M, N, act));
+            int rc = launch_transpose<T>(W, nullptr, Wt, nullptr, N, K, 1.f, 0, st);
+            if (rc) return rc;
+            return launch_gemm<T>((const T*)a, Wt, dx, nullptr, M, K, N, MMGL_ACT_NONE, sc, 0, nullptr, nullptr, 0, st);
         }
         return launch_gemm_tx(false, (const bf16*)W, K, a, N, nullptr, (bf16*)dx, K, M, N, sc, 0, st);
     }
@@ -634,12 +770,12 @@ int linear_wgrad(const T* dy, const T* y, const T* x, T* dW, T* dbias, char* ws,
 
 size_t dgrad_ws(int M, int N, int K, int act, size_t esz) {
     const size_t Np = (size_t)(N + 7) / 8 * 8;
-    if (esz == 2) return act ? align_up((size_t)M * N * esz, 256) : 256;
+    if (esz == 2) return bf16_wt_offset(M, N, act) + align_up((size_t)K * Np * esz, 256);
     return align_up((size_t)K * Np * esz, 256) + (act ? align_up((size_t)M * N * esz, 256) : 0);
 }
 size_t wgrad_ws(int M, int N, int K, size_t esz) {
     const size_t Mp = (size_t)(M + 7) / 8 * 8;
-    if (esz == 2) return align_up((size_t)M * N * esz, 256) + align_up((size_t)COLSUM_SPLITS * N * sizeof(float), 256);
+    if (esz == 2) return align_up((size_t)M * N * esz, 256) + align_up((size_t)COLSUM_SPLITS * N * sizeof(float), 256) + align_up((size_t)K * N * esz, 256);
     return align_up((size_t)N * Mp * esz, 256) + align_up((size_t)K * Mp * esz, 256);
 }
 
@@ -750,7 +886,17 @@ int linear_bwd(const T* dy, const T* y, const T* x, const T* W, T* dx, T* dW, T*
             part = ws + align_up((size_t)M * N * sizeof(T), 256);
         }
         int rc = MMGL_OK;
-        if (dx) rc = launch_gemm_tx(false, (const bf16*)W, K, a, N, nullptr, (bf16*)dx, K, M, N, sc, 0, st);
+        if (dx) {
+            if (tune_gemm_big() && big_tile_shape(M, K, N)) {
+                // large shapes: dx = dyp . (W^T)^T on the 256x256 NT kernel; transposing the [N,K] weight costs a few
+                // percent of the GEMM (it is M/256 times smaller than the activations)
+                T* Wt = (T*)(ws + bf16_wt_offset(M, N, act));
+                rc = launch_transpose<T>(W, nullptr, Wt, nullptr, N, K, 1.f, 0, st);
+                if (!rc) rc = launch_gemm<T>((const T*)a, Wt, dx, nullptr, M, K, N, MMGL_ACT_NONE, sc, 0, nullptr, nullptr, 0, st);
+            } else {
+                rc = launch_gemm_tx(false, (const bf16*)W, K, a, N, nullptr, (bf16*)dx, K, M, N, sc, 0, st);
+            }
+        }
         if (!rc && dW) rc = launch_gemm_tx(true, (const bf16*)x, K, a, N, nullptr, (bf16*)dW, K, N, M, sc, accumulate, st);
         if (!rc && dbias) rc = launch_colsum<T>((const T*)a, nullptr, dbias, (float*)part, M, N, sc, accumulate, st);
         return rc;

@@ -238,6 +238,31 @@ def test_linear(M, N, K, dtype, act):
     assert_close(bd.grad.float(), br.grad, t, "db")
 
 
+@pytest.mark.parametrize("act", ["none", "relu"])
+def test_linear_big_tile_kernels(act):
+    """Shapes large enough for the 256x256 kernels (>= 512 block tiles in forward AND in dgrad), ragged in M and N, checked
+    against a CUDA fp32 matmul of the same bf16 inputs (the CPU reference of the small cases would take minutes here)."""
+    from mmgl_amd import ops
+    M, N, K = 8192 - 37, 4096 - 64, 4096
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(M, K, generator=g).bfloat16().cuda().requires_grad_()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda().requires_grad_()
+    b = (torch.randn(N, generator=g) * 0.3).bfloat16().cuda().requires_grad_()
+    w = torch.randn(M, N, generator=g).bfloat16().cuda()
+    xr, Wr, br = (t.detach().float().requires_grad_() for t in (x, W, b))
+    yr = F.linear(xr, Wr, br)
+    if act == "relu":
+        w = w * (yr.detach().abs() > 5e-2)
+        yr = F.relu(yr)
+    (yr * w.float()).sum().backward()
+    y = ops.linear(x, W, b, act=act)
+    (y * w).sum().backward()
+    assert_close(y.float().cpu(), yr.detach().cpu(), 2e-2, "y")
+    assert_close(x.grad.float().cpu(), xr.grad.cpu(), 2e-2, "dx")
+    assert_close(W.grad.float().cpu(), Wr.grad.cpu(), 2e-2, "dW")
+    assert_close(b.grad.float().cpu(), br.grad.cpu(), 2e-2, "db")
+
+
 def test_linear_a_is_identity_asymmetric():
     """Transpose-detecting check: W = asymmetric matrix, x = identity."""
     from mmgl_amd import ops

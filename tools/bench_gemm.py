@@ -54,6 +54,12 @@ def run(M, N, K, act=0, dtype=torch.bfloat16, iters=30):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        M = int(sys.argv[1])
+        run(M, 2048, 2048)
+        run(M, 8192, 2048, act=1)
+        run(M, 2048, 8192)
+        sys.exit(0)
     for M in (5120, 10240):
         run(M, 2048, 2048)
         run(M, 8192, 2048, act=1)
