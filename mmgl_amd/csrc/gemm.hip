@@ -596,6 +596,141 @@ __global__ __launch_bounds__(256) void gemm_tx_kernel(const bf16* __restrict__ A
     }
 }
 
+// Large-shape weight gradient (bf16): Out[RB][RA] = scale * sum_k B(k, rb) A(k, ra), both operands k-major straight from memory
+// (dW = dyp^T x: A = x [M][K_in], B = dyp [M][N], contraction over the M rows).  256x256 block tile, 8 waves as 4 (A) x 2 (B),
+// wave tile 64 x 128, two K-tile buffers of [64 k][256 cols] per operand kept as two 128-column halves so the tr16 fragment
+// reader and the source-side 32-byte-slot swizzle of gemm_tx_kernel apply unchanged.  Needs RA, RB % 256 == 0, K % 64 == 0.
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void gemm_tt256_kernel(const bf16* __restrict__ Aop, int lda, const bf16* __restrict__ Bop,
+                                                            int ldb, bf16* __restrict__ Out, float* __restrict__ part, int RA, int RB,
+                                                            int K, float scale, int accumulate, int tiles_a, int tiles_b, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HALF = 64 * 256;             // bytes of one [64 k][128 cols] half tile
+    char* sA = smem;                           // [2 buffers][2 halves][HALF]
+    char* sB = smem + 4 * HALF;
+    // split-K for small outputs (a 2048x2048 weight is only 64 tiles): split s contracts rows [s*K/nsplit, (s+1)*K/nsplit) and
+    // writes an fp32 partial tile; splitk_reduce_kernel folds them in a fixed order (deterministic, no atomics)
+    const int vid = xcd_remap(blockIdx.x, tiles_a * tiles_b * nsplit);
+    const int split = vid % nsplit, tile = vid / nsplit;
+    const int ta = tile / tiles_b, tb = tile % tiles_b;
+    const int kchunk = K / nsplit;
+    Aop += (size_t)split * kchunk * lda;
+    Bop += (size_t)split * kchunk * ldb;
+    K = kchunk;
+    const int a0 = ta * 256, b0 = tb * 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = lane & 15, g = lane >> 4;
+    const int wa = wave >> 1, wb = wave & 1;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = vzero<f32x4>();
+
+    auto glds_kmajor = [&](const bf16* op, int ld, int col0, int k0, char* dst) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rbase = (i * 8 + wave) * 4;                          // 4 k-rows (1 KiB) per wave instruction
+                const int row = rbase + (lane >> 4);
+                const int s16 = lane & 15;
+                const int c16 = ((((s16 >> 1) ^ (row & 7)) << 1) | (s16 & 1));
+                const bf16* gp = op + (size_t)(k0 + row) * ld + col0 + h * 128 + c16 * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)(dst + h * HALF + rbase * 256), 16, 0, 0);
+            }
+    };
+    const int nk = K / 64;
+    glds_kmajor(Aop, lda, a0, 0, sA);
+    glds_kmajor(Bop, ldb, b0, 0, sB);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            glds_kmajor(Aop, lda, a0, (kt + 1) * 64, sA + (buf ^ 1) * 2 * HALF);
+            glds_kmajor(Bop, ldb, b0, (kt + 1) * 64, sB + (buf ^ 1) * 2 * HALF);
+        }
+        const char* tA = sA + buf * 2 * HALF;
+        const char* tB = sB + buf * 2 * HALF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int blk = wa * 4 + i;
+                fa[i] = tfrag_kmajor_swz(tA + (blk >> 3) * HALF, blk & 7, ks, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int blk = wb * 8 + j;
+                fb[j] = tfrag_kmajor_swz(tB + (blk >> 3) * HALF, blk & 7, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mma16(acc[i][j], fa[i], fb[j]);
+        }
+        __syncthreads();
+    }
+    if (nsplit > 1) {
+        float* pp = part + (size_t)split * RA * RB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *(f32x4*)(pp + (size_t)(b0 + wb * 128 + j * 16 + x) * RA + a0 + wa * 64 + i * 16 + g * 4) = acc[i][j];
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int rbi = b0 + wb * 128 + j * 16 + x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rai = a0 + wa * 64 + i * 16 + g * 4;
+            f32x4 v = acc[i][j] * scale;
+            bf16* op = Out + (size_t)rbi * RA + rai;
+            if (accumulate) {
+                const bf16x4 ov = *(const bf16x4*)op;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
+            }
+            *(bf16x4*)op = __builtin_convertvector(v, bf16x4);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, bf16* __restrict__ out, size_t n4,
+                                                            int nsplit, float scale, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 a = ((const f32x4*)part)[i];
+        for (int s = 1; s < nsplit; ++s) a += ((const f32x4*)part)[(size_t)s * n4 + i];
+        a *= scale;
+        if (accumulate) {
+            const bf16x4 o = ((const bf16x4*)out)[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] += (float)o[r];
+        }
+        ((bf16x4*)out)[i] = __builtin_convertvector(a, bf16x4);
+    }
+}
+
+// number of K splits of the big weight-gradient kernel (0 = shape not eligible)
+inline int tt256_splits(int RA, int RB, int K) {
+    if (RA % 256 || RB % 256 || K % 64) return 0;
+    const int tiles = (RA / 256) * (RB / 256);
+    if (tiles >= 192) return 1;
+    for (int s = 2; s <= 8; s *= 2)
+        if (tiles * s >= 192 && K % (64 * s) == 0 && K / s >= 1024) return s;
+    return 0;
+}
+inline size_t tt256_partial_bytes(int RA, int RB, int K) {
+    const int s = tt256_splits(RA, RB, K);
+    return s > 1 ? align_up((size_t)s * RA * RB * sizeof(float), 256) : 0;
+}
+
 // column sums of dy (optionally ReLU-masked by y > 0): part[split][N] fp32, then colsum_finish folds the splits.
 template <typename T, bool MASK>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, const T* __restrict__ y, float* __restrict__ part,
@@ -662,9 +797,28 @@ int launch_colsum(const T* dy, const T* y, T* out, float* part, int M, int N, fl
 }
 
 int launch_gemm_tx(bool tb, const bf16* Aop, int lda, const bf16* Bop, int ldb, const bf16* ymask, bf16* Out, int RA, int RB,
-                   int K, float scale, int accumulate, hipStream_t st) {
+                   int K, float scale, int accumulate, hipStream_t st, float* part = nullptr) {
     MMGL_CHECK_ARG(RA > 0 && RB > 0 && K > 0, "gemm_tx: bad sizes");
     if (RA % 8 || (tb ? RB % 8 : K % 8)) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm_tx: feature dims must be multiples of 8");
+    const int nsplit = (tb && !ymask && tune_gemm_big()) ? tt256_splits(RA, RB, K) : 0;
+    if (nsplit == 1 || (nsplit > 1 && part)) {
+        // both operands k-major and a full chip of 256x256 tiles (with K splits for small outputs): the big-tile kernel
+        const int ta = RA / 256, tbn = RB / 256;
+        const size_t ldsb = 8 * 64 * 256;
+        auto kf = gemm_tt256_kernel<0>;
+        hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kf, dim3(ta * tbn * nsplit), dim3(512), ldsb, st, Aop, lda, Bop, ldb, Out, part, RA, RB, K, scale, accumulate,
+                           ta, tbn, nsplit);
+        MMGL_CHECK_LAUNCH("gemm_tt256");
+        if (nsplit > 1) {
+            const size_t n4 = (size_t)RA * RB / 4;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256)), dim3(256), 0, st, part,
+                               Out, n4, nsplit, scale, accumulate);
+            MMGL_CHECK_LAUNCH("splitk_reduce");
+        }
+        return MMGL_OK;
+    }
     const int tiles_a = cdiv(RA, 128), tiles_b = cdiv(RB, 128);
     const size_t lds = 4 * TX_TILE_BYTES;
     // LDS-DMA staging needs whole tiles along every k-major dimension and no ReLU mask (the mask is applied once, upstream)
@@ -699,6 +853,8 @@ int launch_relu_mask(const T* dy, const T* y, T* out, size_t n, float scale, hip
 inline size_t bf16_wt_offset(int M, int N, int act) {
     return (act ? align_up((size_t)M * N * 2, 256) : 0) + align_up((size_t)COLSUM_SPLITS * N * sizeof(float), 256);
 }
+// ... [fp32 split-K partials of the weight gradient (small outputs only)]
+inline size_t bf16_part_offset(int M, int N, int K, int act) { return bf16_wt_offset(M, N, act) + align_up((size_t)K * N * 2, 256); }
 
 template <typename T>
 int linear_dgrad(const T* dy, const T* y, const T* W, T* dx, char* ws, int M, int N, int K, int act, float scale, hipStream_t st) {
@@ -754,7 +910,8 @@ int linear_wgrad(const T* dy, const T* y, const T* x, T* dW, T* dbias, char* ws,
             sc = 1.f;
             part = ws + align_up((size_t)M * N * sizeof(T), 256);
         }
-        int rc = launch_gemm_tx(true, (const bf16*)x, K, a, N, nullptr, (bf16*)dW, K, N, M, sc, accumulate, st);
+        int rc = launch_gemm_tx(true, (const bf16*)x, K, a, N, nullptr, (bf16*)dW, K, N, M, sc, accumulate, st,
+                                (float*)(ws + bf16_part_offset(M, N, K, act)));
         if (rc || !dbias) return rc;
         return launch_colsum<T>((const T*)a, nullptr, dbias, (float*)part, M, N, sc, accumulate, st);
     }
@@ -770,12 +927,12 @@ int linear_wgrad(const T* dy, const T* y, const T* x, T* dW, T* dbias, char* ws,
 
 size_t dgrad_ws(int M, int N, int K, int act, size_t esz) {
     const size_t Np = (size_t)(N + 7) / 8 * 8;
-    if (esz == 2) return bf16_wt_offset(M, N, act) + align_up((size_t)K * Np * esz, 256);
+    if (esz == 2) return bf16_part_offset(M, N, K, act) + tt256_partial_bytes(K, N, M);
     return align_up((size_t)K * Np * esz, 256) + (act ? align_up((size_t)M * N * esz, 256) : 0);
 }
 size_t wgrad_ws(int M, int N, int K, size_t esz) {
     const size_t Mp = (size_t)(M + 7) / 8 * 8;
-    if (esz == 2) return align_up((size_t)M * N * esz, 256) + align_up((size_t)COLSUM_SPLITS * N * sizeof(float), 256) + align_up((size_t)K * N * esz, 256);
+    if (esz == 2) return bf16_part_offset(M, N, K, 1) + tt256_partial_bytes(K, N, M);
     return align_up((size_t)N * Mp * esz, 256) + align_up((size_t)K * Mp * esz, 256);
 }
 
@@ -897,7 +1054,8 @@ int linear_bwd(const T* dy, const T* y, const T* x, const T* W, T* dx, T* dW, T*
                 rc = launch_gemm_tx(false, (const bf16*)W, K, a, N, nullptr, (bf16*)dx, K, M, N, sc, 0, st);
             }
         }
-        if (!rc && dW) rc = launch_gemm_tx(true, (const bf16*)x, K, a, N, nullptr, (bf16*)dW, K, N, M, sc, accumulate, st);
+        if (!rc && dW) rc = launch_gemm_tx(true, (const bf16*)x, K, a, N, nullptr, (bf16*)dW, K, N, M, sc, accumulate, st,
+                                           (float*)(ws + bf16_part_offset(M, N, K, act)));
         if (!rc && dbias) rc = launch_colsum<T>((const T*)a, nullptr, dbias, (float*)part, M, N, sc, accumulate, st);
         return rc;
     } else {

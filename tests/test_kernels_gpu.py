@@ -239,11 +239,12 @@ def test_linear(M, N, K, dtype, act):
 
 
 @pytest.mark.parametrize("act", ["none", "relu"])
-def test_linear_big_tile_kernels(act):
+@pytest.mark.parametrize("M,N,K", [(8192 - 64, 4096, 4096),      # big forward (ragged M), big dgrad, big wgrad (256 tiles)
+                                   (8192, 2048, 2048)])          # 64-tile weight gradient: split-K x4 + fp32 reduce
+def test_linear_big_tile_kernels(act, M, N, K):
     """Shapes large enough for the 256x256 kernels (>= 512 block tiles in forward AND in dgrad), ragged in M and N, checked
     against a CUDA fp32 matmul of the same bf16 inputs (the CPU reference of the small cases would take minutes here)."""
     from mmgl_amd import ops
-    M, N, K = 8192 - 37, 4096 - 64, 4096
     g = torch.Generator().manual_seed(17)
     x = torch.randn(M, K, generator=g).bfloat16().cuda().requires_grad_()
     W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda().requires_grad_()
