@@ -224,26 +224,44 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const bf16* __restri
                                              (__attribute__((address_space(3))) void*)(sW + buf * BIG_TILE_BYTES + rbase * ROWB), 16, 0, 0);
         }
     };
+    // Software pipeline: a K tile is two groups of 32 MFMAs (one per 32-wide k-step).  The fragments of the next group are
+    // requested from LDS before the current group's MFMAs are issued; the one barrier per tile sits BETWEEN the two groups:
+    // by then this wave holds every fragment of tile kt (buffer kt&1 is free: the LDS-DMA of tile kt+2 goes straight into it,
+    // two tiles of prefetch with two buffers) and tile kt+1 has landed (its first fragments load under the second group).
+    auto ld = [&](v8 (&fw)[4], v8 (&fx)[8], const char* tW, const char* tX, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[i] = lds_frag<T>(tW, wn * 64 + i * 16 + x, ks, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fx[j] = lds_frag<T>(tX, wm * 128 + j * 16 + x, ks, g);
+    };
+    auto mm = [&](const v8 (&fw)[4], const v8 (&fx)[8], int i0, int i1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mma16(acc[i][j], fw[i], fx[j]);
+    };
     glds_tile(0, 0);
+    if (nk > 1) glds_tile(1, 1);
     __syncthreads();
+    v8 fwA[4], fxA[8], fwB[4], fxB[8];
+    ld(fwA, fxA, sW, sX, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) glds_tile(kt + 1, buf ^ 1);
-        const char* tX = sX + buf * BIG_TILE_BYTES;
-        const char* tW = sW + buf * BIG_TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < G::KSTEPS; ++ks) {
-            v8 fw[4], fx[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fw[i] = lds_frag<T>(tW, wn * 64 + i * 16 + x, ks, g);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) fx[j] = lds_frag<T>(tX, wm * 128 + j * 16 + x, ks, g);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) mma16(acc[i][j], fw[i], fx[j]);
-        }
-        __syncthreads();
+        // (the LDS counter is in-order and hipcc waits for ALL outstanding reads at the first MFMA of a group, so the next
+        // group's requests go out after the first half of this group's MFMAs rather than before them)
+        mm(fwA, fxA, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        ld(fwB, fxB, sW + buf * BIG_TILE_BYTES, sX + buf * BIG_TILE_BYTES, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(fwA, fxA, 2, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA is ordered by the issuing wave's vmcnt + a barrier: tile kt+1
+        __syncthreads();                                      // has landed for everyone, and this wave's reads of tile kt are done
+        if (kt + 2 < nk) glds_tile(kt + 2, buf);
+        if (kt + 1 < nk) ld(fwA, fxA, sW + (buf ^ 1) * BIG_TILE_BYTES, sX + (buf ^ 1) * BIG_TILE_BYTES, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(fwB, fxB, 0, 4);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -644,36 +662,53 @@ __global__ __launch_bounds__(512, 1) void gemm_tt256_kernel(const bf16* __restri
             }
     };
     const int nk = K / 64;
+    // same software pipeline as gemm_nt256_kernel: fragments one group ahead, one barrier per tile between the two groups,
+    // the LDS-DMA of tile kt+2 issued right after it into the buffer this wave has just finished reading
+    auto ld = [&](bf16x8 (&fa)[4], bf16x8 (&fb)[8], const char* tA, const char* tB, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int blk = wa * 4 + i;
+            fa[i] = tfrag_kmajor_swz(tA + (blk >> 3) * HALF, blk & 7, ks, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int blk = wb * 8 + j;
+            fb[j] = tfrag_kmajor_swz(tB + (blk >> 3) * HALF, blk & 7, ks, lane);
+        }
+    };
+    auto mm = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[8], int i0, int i1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mma16(acc[i][j], fa[i], fb[j]);
+    };
     glds_kmajor(Aop, lda, a0, 0, sA);
     glds_kmajor(Bop, ldb, b0, 0, sB);
+    if (nk > 1) {
+        glds_kmajor(Aop, lda, a0, 64, sA + 2 * HALF);
+        glds_kmajor(Bop, ldb, b0, 64, sB + 2 * HALF);
+    }
     __syncthreads();
+    bf16x8 faA[4], fbA[8], faB[4], fbB[8];
+    ld(faA, fbA, sA, sB, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            glds_kmajor(Aop, lda, a0, (kt + 1) * 64, sA + (buf ^ 1) * 2 * HALF);
-            glds_kmajor(Bop, ldb, b0, (kt + 1) * 64, sB + (buf ^ 1) * 2 * HALF);
-        }
-        const char* tA = sA + buf * 2 * HALF;
-        const char* tB = sB + buf * 2 * HALF;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int blk = wa * 4 + i;
-                fa[i] = tfrag_kmajor_swz(tA + (blk >> 3) * HALF, blk & 7, ks, lane);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int blk = wb * 8 + j;
-                fb[j] = tfrag_kmajor_swz(tB + (blk >> 3) * HALF, blk & 7, ks, lane);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) mma16(acc[i][j], fa[i], fb[j]);
-        }
+        mm(faA, fbA, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        ld(faB, fbB, sA + buf * 2 * HALF, sB + buf * 2 * HALF, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(faA, fbA, 2, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (kt + 2 < nk) {
+            glds_kmajor(Aop, lda, a0, (kt + 2) * 64, sA + buf * 2 * HALF);
+            glds_kmajor(Bop, ldb, b0, (kt + 2) * 64, sB + buf * 2 * HALF);
+        }
+        if (kt + 1 < nk) ld(faA, fbA, sA + (buf ^ 1) * 2 * HALF, sB + (buf ^ 1) * 2 * HALF, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(faB, fbB, 0, 4);
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (nsplit > 1) {
         float* pp = part + (size_t)split * RA * RB;
