@@ -18,7 +18,10 @@ LIB = os.path.join(HERE, "libmmgl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-return-type",
-          "-fno-gpu-rdc", "-munsafe-fp-atomics"]
+          "-fno-gpu-rdc", "-munsafe-fp-atomics",
+          # MFMA accumulators in plain VGPRs: the attention kernels do softmax arithmetic on every accumulator between MFMAs;
+          # with the default AGPR form a quarter of their inner-loop instructions were v_accvgpr_read/write copies
+          "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _newer(src, dst, deps):
