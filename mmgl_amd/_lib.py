@@ -120,6 +120,7 @@ class KernelTimer:
     """Optional per-entry-point timing with HIP events on torch's current stream (= the stream the kernels are launched
     on).  Off by default (zero overhead); bench.py turns it on to price each C-ABI call against its roofline."""
     enabled = False
+    only = None           # optional set of entry-point names: time just these (bench.py's timed region: the roofline kernel)
     records = []          # (name, start_event, end_event, work dict)
 
     @classmethod
@@ -145,7 +146,7 @@ class KernelTimer:
 def call(name: str, work, *args):
     """Invoke C-ABI entry point `name`; raises ValueError / RuntimeError on a non-zero return code."""
     fn = getattr(lib(), name)
-    if KernelTimer.enabled:
+    if KernelTimer.enabled and (KernelTimer.only is None or name in KernelTimer.only):
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
