@@ -10,7 +10,7 @@ B = int(sys.argv[1])
 txt = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/pmc_xattn_B{B}.txt"
 out = sys.argv[3] if len(sys.argv) > 3 else f"profiles/r1_pmc_xattn_B{B}_bf16.json"
 names = {"xattn_fwd_kernel": "xattn_fwd_kernel", "xattn_bwd_dq_kernel": "xattn_bwd_dq_kernel",
-         "xattn_bwd_dkv_kernel": "xattn_bwd_dkv_kernel", "reduce_partials_kernel": "reduce_partials_kernel",
+         "xattn_bwd_dkv_kernel": "xattn_bwd_dkv_kernel", "xattn_bwd_dkv64_kernel": "xattn_bwd_dkv64_kernel", "reduce_partials_kernel": "reduce_partials_kernel",
          "copyBuffer": "calibration_copy"}
 k = {}
 for line in open(txt):
