@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="opt-1.3b", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=48, help="per-GPU batch (reference default 4).  Sized for the 288 GB HBM and the 256-CU GEMM grid: 16 -> 197, 24 -> 212, 48 -> 223, 64 -> 226 samples/s on one MI355X; 48 keeps a step at ~0.2 s")
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (reference default 4).  Sized for the 288 GB HBM and the 256-CU GEMM grid: 16 -> 197, 32 -> 208, 48 -> 233, 56 -> 229, 64 -> 243, 72 -> 233, 80 -> 238 samples/s on one MI355X (the dips are library-GEMM heuristics)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
