@@ -102,6 +102,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     return base + j;
 }
 
+// GEMM tile order: virtual id -> (tm, tn) in bands of GN tile columns walked in groups of GM tile rows, so the GM*GN = 32
+// workgroups an XCD runs at a time cover a GM x GN block: every K slice of an activation tile is fetched into that XCD's L2 once
+// and hit GN-1 times, every K slice of a weight tile hit GM-1 times (the plain column-major order streams the whole activation
+// matrix once per tile COLUMN).  Bijective for any tiles_m, tiles_n.
+__device__ __forceinline__ void grouped_tile(int vid, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GM = 8, GN = 4;
+    int band = vid / (tiles_m * GN);
+    const int last_band = (tiles_n - 1) / GN;
+    band = band > last_band ? last_band : band;
+    const int rem = vid - band * tiles_m * GN;
+    const int ncols = min(GN, tiles_n - band * GN);
+    int grp = rem / (GM * ncols);
+    const int last_grp = (tiles_m - 1) / GM;
+    grp = grp > last_grp ? last_grp : grp;
+    const int r2 = rem - grp * GM * ncols;
+    const int nrows = min(GM, tiles_m - grp * GM);
+    tm = grp * GM + r2 % nrows;
+    tn = band * GN + r2 / nrows;
+}
+
 // Counter-based dropout hash: keep-mask for element i under (seed).  splitmix64 finaliser.
 __device__ __forceinline__ uint32_t mmgl_hash32(uint64_t seed, uint64_t i) {
     uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;

@@ -181,6 +181,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ X, c
 // wave reads 12 KiB of fragments per 32 MFMAs instead of 8 KiB per 16, a K tile keeps each SIMD in MFMAs for ~1000 cycles
 // per wave between barriers (two waves per SIMD cover each other's LDS waits), and the LDS-DMA of tile kt+1 is issued
 // a whole tile ahead.  Same XOR-swizzled 128-byte LDS rows, same epilogue.
+#ifndef MMGL_TILE_GROUPED
+#define MMGL_TILE_GROUPED 1
+#endif
 constexpr int BT = 256;
 constexpr int BIG_TILE_BYTES = BT * ROWB;              // 32 KiB per operand per buffer
 
@@ -195,7 +198,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const bf16* __restri
     char* sX = smem;                           // [2][BIG_TILE_BYTES]
     char* sW = smem + 2 * BIG_TILE_BYTES;      // [2][BIG_TILE_BYTES]
     const int vid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tn = vid / tiles_m, tm = vid % tiles_m;
+    int tm, tn;
+    if (MMGL_TILE_GROUPED) grouped_tile(vid, tiles_m, tiles_n, tm, tn);
+    else { tn = vid / tiles_m; tm = vid % tiles_m; }
     const int m0 = tm * BT, n0 = tn * BT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -630,7 +635,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tt256_kernel(const bf16* __restri
     // writes an fp32 partial tile; splitk_reduce_kernel folds them in a fixed order (deterministic, no atomics)
     const int vid = xcd_remap(blockIdx.x, tiles_a * tiles_b * nsplit);
     const int split = vid % nsplit, tile = vid / nsplit;
-    const int ta = tile / tiles_b, tb = tile % tiles_b;
+    int ta, tb;
+    if (MMGL_TILE_GROUPED) grouped_tile(tile, tiles_b, tiles_a, tb, ta);
+    else { ta = tile / tiles_b; tb = tile % tiles_b; }
     const int kchunk = K / nsplit;
     Aop += (size_t)split * kchunk * lda;
     Bop += (size_t)split * kchunk * ldb;
