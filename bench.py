@@ -185,12 +185,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("MMGL_DIST_BACKEND", "nccl")        # "gloo": dry run of the N-rank path on fewer GPUs than ranks
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} visible GPU(s)")
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from mmgl_amd import _lib
     from mmgl_amd.distributed import DataParallelEngine
