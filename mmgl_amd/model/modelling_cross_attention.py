@@ -497,6 +497,8 @@ class MPTDecoder(MPTPreTrainedModel):
             if isinstance(hidden_states, _Deferred):
                 _, hidden_states = ops.add_layer_norm_pair(hidden_states.branch, hidden_states.residual, fln.weight, fln.bias, fln.eps,
                                                            hidden_states.p_drop, hidden_states.training)
+            elif hidden_states.is_cuda:
+                hidden_states = ops.layer_norm(hidden_states, fln.weight, fln.bias, fln.eps)
             else:
                 hidden_states = fln(hidden_states)
         hidden_states = _materialize(hidden_states)
