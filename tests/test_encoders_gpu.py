@@ -149,3 +149,45 @@ def test_fused_weights_follow_parameter_updates():
     with torch.no_grad():
         ref = model(input_ids=ids, attention_mask=am).last_hidden_state[:, 0]
     assert _rel(b, ref) < 2e-4 and _rel(a, ref) > 1e-3
+
+
+def test_encoder_attention_sequences_are_independent():
+    """Size-independent property at RoBERTa-base width: a sequence's output does not depend on what else is in the pack,
+    nor on where in the pack it sits (bit-exact)."""
+    from mmgl_amd import ops
+    H, D = 12, 64
+    hd = H * D
+    gen = torch.Generator().manual_seed(21)
+    lens_a = torch.tensor([512, 37, 300, 1, 64])
+    lens_b = torch.tensor([5, 300, 512, 129])                   # sequence of length 300 is shared: a[2] == b[1]
+    shared = torch.randn(300, 3 * hd, generator=gen).bfloat16()
+
+    def pack(lens, slot):
+        parts = [torch.randn(int(n), 3 * hd, generator=gen).bfloat16() for n in lens]
+        parts[slot] = shared
+        cu = torch.zeros(len(lens) + 1, dtype=torch.int32)
+        cu[1:] = torch.cumsum(lens, 0)
+        qkv = torch.cat(parts).cuda()
+        out = ops.encoder_attention(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], cu.cuda(), H, int(lens.max()))
+        return out[int(cu[slot]):int(cu[slot + 1])]
+
+    assert torch.equal(pack(lens_a, 2), pack(lens_b, 1))
+
+
+def test_packed_text_encoder_ignores_padding_width():
+    """The packed pass never touches pad tokens: the same sequences padded to a wider L give bit-identical CLS states."""
+    from mmgl_amd.model.encoders import PackedTextEncoder
+    model = _text_model(768, 12, 2, 3072, L=96).bfloat16().cuda()
+    gen = torch.Generator().manual_seed(4)
+    n, L = 6, 48
+    lens = _ragged_lens(n, L, gen)
+    ids = torch.randint(3, 120, (n, L), generator=gen)
+    am = (torch.arange(L)[None] < lens[:, None]).long()
+    ids = torch.where(am.bool(), ids, torch.ones_like(ids))
+    ids[:, 0] = 0
+    wide_ids = torch.cat([ids, torch.ones(n, 40, dtype=ids.dtype)], 1)
+    wide_am = torch.cat([am, torch.zeros(n, 40, dtype=am.dtype)], 1)
+    enc = PackedTextEncoder(model)
+    a = enc.cls(ids.cuda(), am.cuda())
+    b = enc.cls(wide_ids.cuda(), wide_am.cuda())
+    assert torch.equal(a, b)
