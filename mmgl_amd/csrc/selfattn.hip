@@ -693,14 +693,16 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
 // sets swap roles, so nothing is copied -- and dropped into the wave-private tile for the transposed (tr16) reads of
 // dV += P^T dO, dK += dS^T Q.  Branch-free body: bounds by buffer descriptors, masks by selects feeding exp2(-inf) = 0.
 // No barrier, no cross-wave reduction: every dK / dV element is produced by one wave.
-template <int D>
+// NSBW = 16-key blocks per wave: 4 (64 keys) up to D = 64, 2 (32 keys) at D = 128 (the dK / dV accumulators are NSBW * D / 4 registers each)
+template <int D, int NSBW>
 __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ q,
                                                                 const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 const uint8_t* __restrict__ valid, bf16* __restrict__ dk,
                                                                 bf16* __restrict__ dv, int B, int H, int T_, int nkb, int ldq, int ldg) {
     typedef bf16 T;
-    typedef XC<T, D, 4> C;                         // 64 keys = 4 blocks
+    typedef XC<T, D, NSBW> C;
+    constexpr int KW = 16 * NSBW;                  // keys per wave
     typedef bf16x8 v8;
     constexpr int LDT = C::DPAD + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
     const int bh = vid / nkb, kblk = vid % nkb;                 // low key groups (most query tiles) first
     const int b = bh / H, h = bh % H;
     const size_t HD = (size_t)H * D;
-    const int s0 = kblk * 64;
+    const int s0 = kblk * KW;
     const uint32_t rbq = (uint32_t)(ldq * sizeof(T)), rbo = (uint32_t)(HD * sizeof(T));
     const uint32_t slabq = (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T)), slabo = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * ldq + h * D, slabq);
@@ -723,10 +725,10 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(delta + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
 
-    v8 kf[4][C::NDC], vf[4][C::NDC];
-    float kbias[4];                                // 0 for a real, valid key of this lane's column; -inf otherwise
+    v8 kf[NSBW][C::NDC], vf[NSBW][C::NDC];
+    float kbias[NSBW];                                // 0 for a real, valid key of this lane's column; -inf otherwise
 #pragma unroll
-    for (int sbl = 0; sbl < 4; ++sbl) {
+    for (int sbl = 0; sbl < NSBW; ++sbl) {
         const int s = s0 + sbl * 16 + x;
         kbias[sbl] = (s < T_ && valid[(size_t)b * T_ + min(s, T_ - 1)] != 0) ? 0.f : -INFINITY;
 #pragma unroll
@@ -735,11 +737,11 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
             vf[sbl][dc] = buf_load8<T>(rv, row_off<T, C>(s, rbq, dc * 32 + g * 8));
         }
     }
-    f32x4 dva[C::NDB][4], dka[C::NDB][4];
+    f32x4 dva[C::NDB][NSBW], dka[C::NDB][NSBW];
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
-        for (int sbl = 0; sbl < 4; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
+        for (int sbl = 0; sbl < NSBW; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
 
     auto request = [&](int tbase, v8 (&qn)[2][C::NDC], v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
 #pragma unroll
@@ -768,15 +770,15 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
                 *(v8*)(Qt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = qa[tb][dc];
                 *(v8*)(Gt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = ga[tb][dc];
             }
-        const bool diag = t0 < s0 + 63;                         // some (row, key) pair with key > row (wave-uniform)
+        const bool diag = t0 < s0 + KW - 1;                         // some (row, key) pair with key > row (wave-uniform)
         float lt[2][4];
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) lt[tb][r] = (t0 + tb * 16 + g * 4 + r < T_) ? la[tb][r] * LOG2E : INFINITY;   // row past T: p = 0
-        v8 pB[4], dsB[4];
+        v8 pB[NSBW], dsB[NSBW];
 #pragma unroll
-        for (int sbl = 0; sbl < 4; ++sbl) {
+        for (int sbl = 0; sbl < NSBW; ++sbl) {
             f32x4 pr[2], dsr[2];
             const int s = s0 + sbl * 16 + x;
 #pragma unroll
@@ -813,7 +815,7 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
             const v8 gT = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
             const v8 qT = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
 #pragma unroll
-            for (int sbl = 0; sbl < 4; ++sbl) {
+            for (int sbl = 0; sbl < NSBW; ++sbl) {
                 mma16(dva[db][sbl], gT, pB[sbl]);
                 mma16(dka[db][sbl], qT, dsB[sbl]);
             }
@@ -830,7 +832,7 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
         if (t0 + 32 < T_) step(t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
     }
 #pragma unroll
-    for (int sbl = 0; sbl < 4; ++sbl) {
+    for (int sbl = 0; sbl < NSBW; ++sbl) {
         const int s = s0 + sbl * 16 + x;
         if (s < T_) {
             const size_t off = ((size_t)b * T_ + s) * ldg + h * D + g * 4;
@@ -900,12 +902,13 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
             return sizeof(T) * 4 * C::ROWIMG + tiles;
         };
         static const int use64 = [] { const char* e = getenv("MMGL_SELFATTN_DKV64"); return e ? atoi(e) : 1; }();
-        if constexpr (sizeof(T) == 2 && D <= 64) {
+        if constexpr (sizeof(T) == 2) {
             if (use64) {
-                typedef XC<bf16, D, 4> C4;
-                const int nkb64 = cdiv(T_, 64);
+                constexpr int NSBW = D <= 64 ? 4 : 2;
+                typedef XC<bf16, D, NSBW> C4;
+                const int nkb64 = cdiv(T_, 16 * NSBW);
                 const size_t lds64 = sizeof(bf16) * 2 * 32 * (C4::DPAD + 16);
-                hipLaunchKernelGGL((selfattn_bwd_dkv64_kernel<D>), dim3(B * H * nkb64), dim3(64), lds64, st, (const bf16*)dout,
+                hipLaunchKernelGGL((selfattn_bwd_dkv64_kernel<D, NSBW>), dim3(B * H * nkb64), dim3(64), lds64, st, (const bf16*)dout,
                                    (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, (bf16*)dk, (bf16*)dv, B, H, T_,
                                    nkb64, ldq, ldg);
                 MMGL_CHECK_LAUNCH("selfattn_bwd_dkv64");

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64) void xattn_bwd_dkv_kernel(const T* __restrict__
 // K / V fragments loaded once into registers, Q / dO row fragments + LSE + delta requested one tile ahead into a second
 // register set (loop unrolled by two, the sets swap roles), branch-free body (buffer-descriptor bounds, masks as selects
 // feeding exp2(-inf) = 0), Q^T / dO^T from the wave-private tile via ds_read_b64_tr_b16.  Same fp32 partial layout as above.
-template <int D>
+template <int D, int NSBW>
 __global__ __launch_bounds__(64) void xattn_bwd_dkv64_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ q,
                                                              const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
@@ -528,7 +528,8 @@ __global__ __launch_bounds__(64) void xattn_bwd_dkv64_kernel(const bf16* __restr
                                                              float* __restrict__ dv_part, int B, int H, int T_, int S,
                                                              int nsg, int rows_per_chunk, int nchunk) {
     typedef bf16 T;
-    typedef XC<T, D, 4> C;
+    typedef XC<T, D, NSBW> C;
+    constexpr int KW = 16 * NSBW;                  // keys per wave: 64 up to D = 64, 32 at D = 128
     typedef bf16x8 v8;
     constexpr int LDT = C::DPAD + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(64) void xattn_bwd_dkv64_kernel(const bf16* __restr
     const int bh = vid / (nchunk * nsg);
     const int b = bh / H, h = bh % H;
     const size_t HD = (size_t)H * D;
-    const int s0 = sg * 64;
+    const int s0 = sg * KW;
     const int row_begin = chunk * rows_per_chunk, row_end = min(row_begin + rows_per_chunk, T_);
 
     const uint32_t rb = (uint32_t)(HD * sizeof(T));
@@ -558,10 +559,10 @@ __global__ __launch_bounds__(64) void xattn_bwd_dkv64_kernel(const bf16* __restr
     const bool any_valid = __ballot(any) != 0ull;
     const float uni = 1.f / (float)S, tie = any_valid ? 1.f : 0.5f;
 
-    v8 kf[4][C::NDC], vf[4][C::NDC];
-    float kbias[4], kuni[4];                       // valid key: 0 / -inf;  existing key: 1/S / 0 (sample without any valid key)
+    v8 kf[NSBW][C::NDC], vf[NSBW][C::NDC];
+    float kbias[NSBW], kuni[NSBW];                       // valid key: 0 / -inf;  existing key: 1/S / 0 (sample without any valid key)
 #pragma unroll
-    for (int sbl = 0; sbl < 4; ++sbl) {
+    for (int sbl = 0; sbl < NSBW; ++sbl) {
         const int s = s0 + sbl * 16 + x;
         kbias[sbl] = (s < S && valid[(size_t)b * S + min(s, S - 1)] != 0) ? 0.f : -INFINITY;
         kuni[sbl] = s < S ? uni : 0.f;
@@ -571,11 +572,11 @@ __global__ __launch_bounds__(64) void xattn_bwd_dkv64_kernel(const bf16* __restr
             vf[sbl][dc] = buf_load8<T>(rv, row_off<T, C>(s, rb, dc * 32 + g * 8));
         }
     }
-    f32x4 dva[C::NDB][4], dka[C::NDB][4];
+    f32x4 dva[C::NDB][NSBW], dka[C::NDB][NSBW];
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
-        for (int sbl = 0; sbl < 4; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
+        for (int sbl = 0; sbl < NSBW; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
 
     auto request = [&](int tbase, v8 (&qn)[2][C::NDC], v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
 #pragma unroll
@@ -612,9 +613,9 @@ __global__ __launch_bounds__(64) void xattn_bwd_dkv64_kernel(const bf16* __restr
                 lt[tb][r] = tv ? la[tb][r] * LOG2E : INFINITY;
                 rowu[tb][r] = tv ? 1.f : 0.f;
             }
-        v8 pB[4], dsB[4];
+        v8 pB[NSBW], dsB[NSBW];
 #pragma unroll
-        for (int sbl = 0; sbl < 4; ++sbl) {
+        for (int sbl = 0; sbl < NSBW; ++sbl) {
             f32x4 pr[2], dsr[2];
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(64) void xattn_bwd_dkv64_kernel(const bf16* __restr
             const v8 gT = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
             const v8 qT = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
 #pragma unroll
-            for (int sbl = 0; sbl < 4; ++sbl) {
+            for (int sbl = 0; sbl < NSBW; ++sbl) {
                 mma16(dva[db][sbl], gT, pB[sbl]);
                 mma16(dka[db][sbl], qT, dsB[sbl]);
             }
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(64) void xattn_bwd_dkv64_kernel(const bf16* __restr
         if (t0 + 32 < row_end) step(t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
     }
 #pragma unroll
-    for (int sbl = 0; sbl < 4; ++sbl) {
+    for (int sbl = 0; sbl < NSBW; ++sbl) {
         const int s = s0 + sbl * 16 + x;
         if (s < S) {
             const size_t off = (((size_t)chunk * B + b) * S + s) * HD + h * D + g * 4;
@@ -696,12 +697,13 @@ struct BwdPlan { int nsg, nchunk, rows_per_chunk; size_t delta_off, dk_off, dv_o
 // keys per dK/dV wave: 64 for the bf16 D <= 64 kernel, 32 for the generic one
 inline bool use_dkv64(int D, size_t esz) {
     static const int on = [] { const char* e = getenv("MMGL_XATTN_DKV64"); return e ? atoi(e) : 1; }();
-    return on && esz == 2 && D <= 64;
+    return on && esz == 2;
 }
+inline int dkv64_keys(int D) { return D <= 64 ? 64 : 32; }
 
 BwdPlan bwd_plan(int B, int H, int T, int S, int D, size_t esz = 2) {
     BwdPlan p;
-    p.nsg = use_dkv64(D, esz) ? (S + 63) / 64 : (S + 31) / 32;
+    p.nsg = use_dkv64(D, esz) ? (S + dkv64_keys(D) - 1) / dkv64_keys(D) : (S + 31) / 32;
     long units = (long)B * H * p.nsg;
     int nchunk = (int)((2048 + units - 1) / units);
     int maxchunk = (T + 63) / 64;
@@ -781,11 +783,12 @@ int launch_bwd(const void* dout, const void* q, const void* k, const void* v, co
         MMGL_CHECK_LAUNCH("xattn_bwd_dq");
     }
     bool done64 = false;
-    if constexpr (sizeof(T) == 2 && D <= 64) {
+    if constexpr (sizeof(T) == 2) {
         if (use_dkv64(D, sizeof(T))) {
-            typedef XC<bf16, D, 4> C4;
+            constexpr int NSBW = D <= 64 ? 4 : 2;
+            typedef XC<bf16, D, NSBW> C4;
             const size_t lds = sizeof(bf16) * 2 * 32 * (C4::DPAD + 16);
-            hipLaunchKernelGGL((xattn_bwd_dkv64_kernel<D>), dim3(B * H * p.nsg * p.nchunk), dim3(64), lds, st, (const bf16*)dout,
+            hipLaunchKernelGGL((xattn_bwd_dkv64_kernel<D, NSBW>), dim3(B * H * p.nsg * p.nchunk), dim3(64), lds, st, (const bf16*)dout,
                                (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, dkp, dvp, B, H, T_, S, p.nsg,
                                p.rows_per_chunk, p.nchunk);
             MMGL_CHECK_LAUNCH("xattn_bwd_dkv64");
