@@ -256,22 +256,32 @@ __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const T* __restrict__
 
     const int wg_begin = chunk * rows_per_wg;
     const int wg_end = min(wg_begin + rows_per_wg, T_);
-    const T* qb = q + (size_t)b * T_ * HD + h * D;
-    const T* gb = dout + (size_t)b * T_ * HD + h * D;
-    T* dqb = dq + (size_t)b * T_ * HD + h * D;
-    const float* lb = lse + (size_t)bh * T_;
-    float* db_ = delta + (size_t)bh * T_;
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t slab = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(dout + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dq + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t rdl = make_rsrc(delta + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
 
+    // same memory pipeline as the forward kernel: bounds-checked buffer accesses (no branches), per wave in VMEM order
+    //   stores(i-1), loads(i+1), compute(i)
     int t0 = wg_begin + wave * TILE;
     v8 qn[C::QT][C::NDC], gn[C::QT][C::NDC];
+    float lsn[C::QT];
+    auto request = [&](int tbase, bool live) __attribute__((always_inline)) {
 #pragma unroll
-    for (int qt = 0; qt < C::QT; ++qt)
+        for (int qt = 0; qt < C::QT; ++qt) {
+            const int t = live ? tbase + qt * 16 + x : T_;
 #pragma unroll
-        for (int dc = 0; dc < C::NDC; ++dc) {
-            const int t = (t0 < wg_end) ? t0 + qt * 16 + x : T_;
-            qn[qt][dc] = load_qfrag<T, C>(qb, t, T_, HD, dc * 32 + g * 8);
-            gn[qt][dc] = load_qfrag<T, C>(gb, t, T_, HD, dc * 32 + g * 8);
+            for (int dc = 0; dc < C::NDC; ++dc) {
+                qn[qt][dc] = buf_load8<T>(rq, row_off<T, C>(t, row_bytes, dc * 32 + g * 8));
+                gn[qt][dc] = buf_load8<T>(rg, row_off<T, C>(t, row_bytes, dc * 32 + g * 8));
+            }
+            lsn[qt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (uint32_t)t * 4u, 0, 0));
         }
+    };
+    request(t0, t0 < wg_end);
 
     if constexpr (C::TIMG) stage_rowmajor_image<T, C>(Ki, k + (size_t)b * S * HD + h * D, HD, S);
     else stage_row_image<T, C>(Ki, k + (size_t)b * S * HD + h * D, HD, S);
@@ -284,25 +294,41 @@ __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const T* __restrict__
     const bool any_valid = __ballot((vlo | vhi) != 0) != 0ull;
     const float uni = 1.f / (float)S;
     const float tie = any_valid ? 1.f : 0.5f;                 // autograd's 50/50 split at the torch.max tie
+    f32x4 bias[C::NSB];
+    key_bias<C>(vlo, vhi, bias);                              // 0 / -inf per key: the mask enters as the MFMA C input
 
+    typedef typename Elem<T>::v4 v4;
+    v4 ost[C::QT][C::NDB];
+    float dst[C::QT];
+    int tprev = T_;
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        dst[qt] = 0.f;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) ost[qt][db] = vzero<v4>();
+    }
+    auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int qt = 0; qt < C::QT; ++qt) {
+            const int t = tprev + qt * 16 + x;
+            store_row_tiles<T, C>(rd, t, T_, row_bytes, g, ost[qt]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, dst[qt]), rdl, (g == 0) ? (uint32_t)t * 4u : OOB, 0, 0);
+        }
+    };
     for (; t0 < wg_end; t0 += 4 * TILE) {
         if constexpr (!C::HOIST) asm volatile("" ::: "memory");
         v8 qf[C::QT][C::NDC], gf[C::QT][C::NDC];
-        float lset[C::QT];
-        const int tn = t0 + 4 * TILE;
+        float l2[C::QT];
 #pragma unroll
         for (int qt = 0; qt < C::QT; ++qt) {
-            const int t = t0 + qt * 16 + x;
-            lset[qt] = (t < T_) ? lb[t] : 0.f;
-            const int tp = (tn < wg_end) ? tn + qt * 16 + x : T_;
+            l2[qt] = lsn[qt] * LOG2E;
 #pragma unroll
-            for (int dc = 0; dc < C::NDC; ++dc) {
-                qf[qt][dc] = qn[qt][dc];
-                gf[qt][dc] = gn[qt][dc];
-                qn[qt][dc] = load_qfrag<T, C>(qb, tp, T_, HD, dc * 32 + g * 8);
-                gn[qt][dc] = load_qfrag<T, C>(gb, tp, T_, HD, dc * 32 + g * 8);
-            }
+            for (int dc = 0; dc < C::NDC; ++dc) { qf[qt][dc] = qn[qt][dc]; gf[qt][dc] = gn[qt][dc]; }
         }
+        flush();
+        tprev = t0;
+        request(t0 + 4 * TILE, t0 + 4 * TILE < wg_end);
+
         v8 dsf[C::QT][C::NKS];
         float dlt[C::QT];
         {
@@ -310,7 +336,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const T* __restrict__
 #pragma unroll
             for (int sb = 0; sb < C::NSB; ++sb) {
 #pragma unroll
-                for (int qt = 0; qt < C::QT; ++qt) { sacc[qt][sb] = vzero<f32x4>(); pacc[qt][sb] = vzero<f32x4>(); }
+                for (int qt = 0; qt < C::QT; ++qt) { sacc[qt][sb] = bias[sb]; pacc[qt][sb] = vzero<f32x4>(); }
 #pragma unroll
                 for (int dc = 0; dc < C::NDC; ++dc) {
                     v8 kf;
@@ -332,13 +358,12 @@ __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const T* __restrict__
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float p;
-                        if (any_valid) p = bit64(vlo, vhi, sb * 4 + r) ? __expf(sacc[qt][sb][r] - lset[qt]) : 0.f;
+                        if (any_valid) p = __builtin_amdgcn_exp2f(fmaf(sacc[qt][sb][r], LOG2E, -l2[qt]));    // masked key: exp2(-inf) = 0
                         else p = bit64(elo, ehi, sb * 4 + r) ? uni : 0.f;
                         sacc[qt][sb][r] = p;
                         dl += p * pacc[qt][sb][r];
                     }
-                dl += __shfl_xor(dl, 16);
-                dl += __shfl_xor(dl, 32);
+                dl = xg_sum(dl);
                 dlt[qt] = dl;
 #pragma unroll
                 for (int sb = 0; sb < C::NSB; ++sb)
@@ -364,14 +389,12 @@ __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const T* __restrict__
         }
 #pragma unroll
         for (int qt = 0; qt < C::QT; ++qt) {
-            const int t = t0 + qt * 16 + x;
-            if (t < T_) {
+            dst[qt] = dlt[qt];
 #pragma unroll
-                for (int db = 0; db < C::NDB; ++db) store4<T>(dqb + (size_t)t * HD + db * 16 + g * 4, acc[qt][db]);
-                if (g == 0) db_[t] = dlt[qt];
-            }
+            for (int db = 0; db < C::NDB; ++db) ost[qt][db] = cvt4<T>(acc[qt][db]);
         }
     }
+    flush();                                                  // the last tile's outputs
 }
 
 // ============================================================================================ backward 2: dK, dV partials
