@@ -145,11 +145,14 @@ size_t mmgl_linear_wgrad_workspace(int M, int N, int K, int dtype);
 int mmgl_linear_wgrad(const void* dy, const void* y, const void* x, void* dW, void* dbias, void* workspace,
                       size_t workspace_bytes, int M, int N, int K, int act, float out_scale, int accumulate,
                       int dtype, void* stream);
-/* Whole backward of one linear in a single call: dyp is formed once, then dx / dW / dbias (each may be NULL). */
+/* Whole backward of one linear in a single call: dyp is formed once, then dx / dW / dbias (each may be NULL).
+ * mask_dx != 0: x is itself the output of a ReLU (fc2 after fc1+ReLU, modelling_cross_attention.py:352-355) and that ReLU's
+ * backward is folded into this call: dx is zeroed where x <= 0 (in the dgrad GEMM's epilogue for the large-shape kernel), so
+ * the producing linear can be differentiated with act = none on the already-masked gradient. */
 size_t mmgl_linear_bwd_workspace(int M, int N, int K, int act, int dtype);
 int mmgl_linear_bwd(const void* dy, const void* y, const void* x, const void* W, void* dx, void* dW, void* dbias,
                     void* workspace, size_t workspace_bytes, int M, int N, int K, int act, float out_scale,
-                    int accumulate, int dtype, void* stream);
+                    int accumulate, int mask_dx, int dtype, void* stream);
 /* out[C,ld] = in[R,C]^T, ld = R rounded up to a whole 16-byte chunk (zero padded) */
 int mmgl_transpose(const void* in, void* out, int R, int C, int dtype, void* stream);
 

@@ -43,7 +43,7 @@ SIGNATURES = {
     "mmgl_linear_wgrad_workspace": (Z, [I, I, I, I]),
     "mmgl_linear_wgrad": (I, [P, P, P, P, P, P, Z, I, I, I, I, F, I, I, P]),
     "mmgl_linear_bwd_workspace": (Z, [I, I, I, I, I]),
-    "mmgl_linear_bwd": (I, [P, P, P, P, P, P, P, P, Z, I, I, I, I, F, I, I, P]),
+    "mmgl_linear_bwd": (I, [P, P, P, P, P, P, P, P, Z, I, I, I, I, F, I, I, I, P]),
     "mmgl_transpose": (I, [P, P, I, I, I, P]),
     "mmgl_lora_linear_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P]),
     "mmgl_lora_linear_bwd_workspace": (Z, [I, I, I, I, I]),

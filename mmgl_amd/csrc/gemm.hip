@@ -190,7 +190,8 @@ constexpr int BIG_TILE_BYTES = BT * ROWB;              // 32 KiB per operand per
 template <int ACT>
 __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
                                                             bf16* __restrict__ Y, const bf16* __restrict__ bias, int M, int N,
-                                                            int K, float scale, int accumulate, int tiles_m, int tiles_n) {
+                                                            int K, float scale, int accumulate, int tiles_m, int tiles_n,
+                                                            const bf16* __restrict__ zmask) {
     typedef bf16 T;
     typedef GT<T> G;
     typedef bf16x8 v8;
@@ -293,6 +294,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const bf16* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
             }
+            if (zmask) {                                      // ReLU backward of the producer of this GEMM's output-side operand
+                const bf16x4 mv = *(const bf16x4*)(zmask + (size_t)m * N + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = ((float)mv[r] > 0.f) ? v[r] : 0.f;
+            }
             *(bf16x4*)yp = __builtin_convertvector(v, bf16x4);
         }
     }
@@ -374,7 +380,7 @@ template <typename T> inline int pad_k(int k) { return (k + GT<T>::VN - 1) / GT<
 
 template <typename T>
 int launch_gemm(const T* X, const T* W, T* Y, const T* bias, int M, int N, int K, int act, float scale, int accumulate,
-                const T* X2, const T* W2, int K2, hipStream_t st) {
+                const T* X2, const T* W2, int K2, hipStream_t st, const T* zmask = nullptr, bool* zmask_done = nullptr) {
     constexpr int VN = GT<T>::VN;
     MMGL_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: M,N,K must be positive (got %d,%d,%d)", M, N, K);
     if (K % VN || N % 4 || (X2 && K2 % VN))
@@ -388,10 +394,11 @@ int launch_gemm(const T* X, const T* W, T* Y, const T* bias, int M, int N, int K
             hipError_t eb = hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
             if (eb != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(eb));
             if (act == MMGL_ACT_RELU)
-                hipLaunchKernelGGL((gemm_nt256_kernel<MMGL_ACT_RELU>), dim3(tm * tn), dim3(512), ldsb, st, X, W, Y, bias, M, N, K, scale, accumulate, tm, tn);
+                hipLaunchKernelGGL((gemm_nt256_kernel<MMGL_ACT_RELU>), dim3(tm * tn), dim3(512), ldsb, st, X, W, Y, bias, M, N, K, scale, accumulate, tm, tn, (const bf16*)zmask);
             else
-                hipLaunchKernelGGL((gemm_nt256_kernel<MMGL_ACT_NONE>), dim3(tm * tn), dim3(512), ldsb, st, X, W, Y, bias, M, N, K, scale, accumulate, tm, tn);
+                hipLaunchKernelGGL((gemm_nt256_kernel<MMGL_ACT_NONE>), dim3(tm * tn), dim3(512), ldsb, st, X, W, Y, bias, M, N, K, scale, accumulate, tm, tn, (const bf16*)zmask);
             MMGL_CHECK_LAUNCH("gemm_nt256");
+            if (zmask_done) *zmask_done = zmask != nullptr;
             return MMGL_OK;
         }
     }
@@ -1072,7 +1079,9 @@ extern "C" int mmgl_linear_wgrad(const void* dy, const void* y, const void* x, v
 // One call for the whole backward of a linear: dyp once, then dx / dW / dbias as requested (any of them may be NULL).
 template <typename T>
 int linear_bwd(const T* dy, const T* y, const T* x, const T* W, T* dx, T* dW, T* dbias, char* ws, int M, int N, int K, int act,
-               float scale, int accumulate, hipStream_t st) {
+               float scale, int accumulate, hipStream_t st, bool mask_dx = false) {
+    // mask_dx: x is the output of a ReLU; its backward (dx = 0 where x <= 0) is folded into this dgrad -- the epilogue of the
+    // 256x256 kernel, or one in-place pass after the other GEMM forms
     if constexpr (sizeof(T) == 2) {
         const bf16* a = (const bf16*)dy;
         float sc = scale;
@@ -1091,9 +1100,13 @@ int linear_bwd(const T* dy, const T* y, const T* x, const T* W, T* dx, T* dW, T*
                 // percent of the GEMM (it is M/256 times smaller than the activations)
                 T* Wt = (T*)(ws + bf16_wt_offset(M, N, act));
                 rc = launch_transpose<T>(W, nullptr, Wt, nullptr, N, K, 1.f, 0, st);
-                if (!rc) rc = launch_gemm<T>((const T*)a, Wt, dx, nullptr, M, K, N, MMGL_ACT_NONE, sc, 0, nullptr, nullptr, 0, st);
+                bool masked = false;
+                if (!rc) rc = launch_gemm<T>((const T*)a, Wt, dx, nullptr, M, K, N, MMGL_ACT_NONE, sc, 0, nullptr, nullptr, 0, st,
+                                             mask_dx ? x : nullptr, &masked);
+                if (!rc && mask_dx && !masked) rc = launch_relu_mask<T>(dx, x, dx, (size_t)M * K, 1.f, st);
             } else {
                 rc = launch_gemm_tx(false, (const bf16*)W, K, a, N, nullptr, (bf16*)dx, K, M, N, sc, 0, st);
+                if (!rc && mask_dx) rc = launch_relu_mask<T>(dx, x, dx, (size_t)M * K, 1.f, st);
             }
         }
         if (!rc && dW) rc = launch_gemm_tx(true, (const bf16*)x, K, a, N, nullptr, (bf16*)dW, K, N, M, sc, accumulate, st,
@@ -1103,6 +1116,7 @@ int linear_bwd(const T* dy, const T* y, const T* x, const T* W, T* dx, T* dW, T*
     } else {
         int rc = MMGL_OK;
         if (dx) rc = linear_dgrad<T>(dy, y, W, dx, ws, M, N, K, act, scale, st);
+        if (!rc && dx && mask_dx) rc = launch_relu_mask<T>(dx, x, dx, (size_t)M * K, 1.f, st);
         if (!rc && (dW || dbias)) {
             MMGL_CHECK_ARG(dW, "mmgl_linear_bwd: fp32 path needs dW when dbias is requested");
             rc = linear_wgrad<T>(dy, y, x, dW, dbias, ws, M, N, K, act, scale, accumulate, st);
@@ -1119,14 +1133,14 @@ extern "C" size_t mmgl_linear_bwd_workspace(int M, int N, int K, int act, int dt
 
 extern "C" int mmgl_linear_bwd(const void* dy, const void* y, const void* x, const void* W, void* dx, void* dW, void* dbias,
                                void* workspace, size_t workspace_bytes, int M, int N, int K, int act, float out_scale,
-                               int accumulate, int dtype, void* stream) {
+                               int accumulate, int mask_dx, int dtype, void* stream) {
     MMGL_CHECK_ARG(dy && x && W && workspace && (act == MMGL_ACT_NONE || y), "mmgl_linear_bwd: null pointer");
     MMGL_CHECK_ARG(workspace_bytes >= mmgl_linear_bwd_workspace(M, N, K, act, dtype), "mmgl_linear_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     DT_SWITCH("mmgl_linear_bwd",
-              linear_bwd<bf16>((const bf16*)dy, (const bf16*)y, (const bf16*)x, (const bf16*)W, (bf16*)dx, (bf16*)dW, (bf16*)dbias, ws, M, N, K, act, out_scale, accumulate, st),
-              linear_bwd<float>((const float*)dy, (const float*)y, (const float*)x, (const float*)W, (float*)dx, (float*)dW, (float*)dbias, ws, M, N, K, act, out_scale, accumulate, st));
+              linear_bwd<bf16>((const bf16*)dy, (const bf16*)y, (const bf16*)x, (const bf16*)W, (bf16*)dx, (bf16*)dW, (bf16*)dbias, ws, M, N, K, act, out_scale, accumulate, st, mask_dx != 0),
+              linear_bwd<float>((const float*)dy, (const float*)y, (const float*)x, (const float*)W, (float*)dx, (float*)dW, (float*)dbias, ws, M, N, K, act, out_scale, accumulate, st, mask_dx != 0));
 }
 
 extern "C" int mmgl_lora_linear_fwd(const void* x, const void* W, const void* bias, const void* A, const void* Bm, void* y,

@@ -278,10 +278,12 @@ class MPTDecoderLayer(nn.Module):
         residual = h
         x = self._ln(self.final_layer_norm, h) if self.do_layer_norm_before else h
         if self.activation_name == "relu":
-            x = ops.linear(x, self.fc1.weight, self.fc1.bias, act="relu")
+            # fc1's ReLU backward rides in the epilogue of fc2's dgrad GEMM (mask_dx) instead of a separate pass over [M, ffn]
+            x = ops.linear(x, self.fc1.weight, self.fc1.bias, act="relu", bwd_premasked=True)
+            x = ops.linear(x, self.fc2.weight, self.fc2.bias, mask_dx=True)
         else:
             x = self.activation_fn(ops.linear(x, self.fc1.weight, self.fc1.bias))
-        x = ops.linear(x, self.fc2.weight, self.fc2.bias)
+            x = ops.linear(x, self.fc2.weight, self.fc2.bias)
         h = ops.gated_residual(residual, x, self.gating2 if gated else None, self.dropout, self.training)
         if not self.do_layer_norm_before:
             h = self._ln(self.final_layer_norm, h)

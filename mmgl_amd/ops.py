@@ -351,7 +351,7 @@ def gated_residual(residual, x, gate=None, p_drop=0.0, training=False, seed=None
 # ------------------------------------------------------------------------------------------ linear (+bias, scale, ReLU)
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act, out_scale):
+    def forward(ctx, x, weight, bias, act, out_scale, mask_dx=False, premasked=False):
         require_cuda(x, weight)
         shape = x.shape
         K = shape[-1]
@@ -362,8 +362,11 @@ class _Linear(torch.autograd.Function):
         b = None if bias is None else bias.to(x.dtype).contiguous()
         y = torch.empty(M, N, dtype=x.dtype, device=x.device)
         _lib.call("mmgl_linear_fwd", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x.element_size()), ptr(x2), ptr(w), ptr(b), ptr(y), M, N, K, act, out_scale, dtype_code(x), stream_ptr())
-        ctx.save_for_backward(x2, w, y if act else None)
-        ctx.meta = (shape, act, out_scale, weight.dtype, None if bias is None else bias.dtype)
+        # premasked: the consumer of y folds this layer's ReLU backward into its own dgrad (mask_dx there), so the incoming
+        # gradient is already dy * (y > 0): differentiate as a plain linear and do not keep y for the mask
+        ctx.save_for_backward(x2, w, y if (act and not premasked) else None)
+        ctx.meta = (shape, 0 if premasked else act, out_scale, weight.dtype, None if bias is None else bias.dtype)
+        ctx.mask_dx = bool(mask_dx)
         ctx.need = (x.requires_grad, weight.requires_grad, bias is not None and bias.requires_grad)
         return y.view(*shape[:-1], N)
 
@@ -382,18 +385,21 @@ class _Linear(torch.autograd.Function):
         ws = _ws(lib().mmgl_linear_bwd_workspace(M, N, K, act, code), x2.device)
         _lib.call("mmgl_linear_bwd", dict(flops=2.0 * M * N * K * (int(dx is not None) + int(dw is not None)),
                                          bytes=float(M * K + N * K + M * N) * x2.element_size()),
-                  ptr(dy2), ptr(y), ptr(x2), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), ws.numel(), M, N, K, act, out_scale, 0, code,
-                  stream_ptr())
+                  ptr(dy2), ptr(y), ptr(x2), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), ws.numel(), M, N, K, act, out_scale, 0,
+                  int(ctx.mask_dx), code, stream_ptr())
         if dx is not None:
             dx = dx.view(shape)
         dw = dw.to(wdt) if (dw is not None and ctx.need[1]) else None
         db = db.to(bdt) if db is not None else None
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def linear(x, weight, bias=None, act="none", out_scale=1.0):
+def linear(x, weight, bias=None, act="none", out_scale=1.0, mask_dx=False, bwd_premasked=False):
     """act((x @ weight.T + bias) * out_scale); weight is nn.Linear layout [out, in].
-    (reference q/k/v/out_proj :194-199, :273; fc1+ReLU / fc2 :352-355)"""
+    (reference q/k/v/out_proj :194-199, :273; fc1+ReLU / fc2 :352-355)
+    mask_dx / bwd_premasked: a ReLU linear followed directly by another linear can hand its ReLU backward to the consumer:
+    `h = linear(x, W1, b1, act="relu", bwd_premasked=True); y = linear(h, W2, b2, mask_dx=True)` -- the second call zeroes
+    its dx where h <= 0 inside the dgrad GEMM, the first one then skips the separate mask pass.  Use the two flags together."""
     if x.shape[-1] != weight.shape[1]:
         raise ValueError(f"linear: x has {x.shape[-1]} features, weight expects {weight.shape[1]}")
     code = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU}.get(act)
@@ -409,9 +415,9 @@ def linear(x, weight, bias=None, act="none", out_scale=1.0):
         weight = torch.nn.functional.pad(weight, (0, pk, 0, pn))
         if bias is not None and pn:
             bias = torch.nn.functional.pad(bias, (0, pn))
-        y = _Linear.apply(x, weight, bias, code, float(out_scale))
+        y = _Linear.apply(x, weight, bias, code, float(out_scale), bool(mask_dx), bool(bwd_premasked))
         return y[..., :N] if pn else y
-    return _Linear.apply(x, weight, bias, code, float(out_scale))
+    return _Linear.apply(x, weight, bias, code, float(out_scale), bool(mask_dx), bool(bwd_premasked))
 
 
 class _LoraLinear(torch.autograd.Function):

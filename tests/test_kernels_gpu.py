@@ -264,6 +264,33 @@ def test_linear_big_tile_kernels(act, M, N, K):
     assert_close(b.grad.float().cpu(), br.grad.cpu(), 2e-2, "db")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,F_", [(300, 64, 136), (8192, 2048, 4096)])
+def test_linear_relu_pair_with_folded_mask(dtype, M, K, F_):
+    """fc1+ReLU -> fc2 with fc1's ReLU backward folded into fc2's dgrad (bwd_premasked / mask_dx) must give the same
+    gradients as the plain pair (the large case runs the 256x256 kernels' mask epilogue, the small one the in-place pass)."""
+    from mmgl_amd import ops
+    if dtype == torch.float32 and M > 1000:
+        pytest.skip("large case: bf16 kernels only")
+    g = torch.Generator().manual_seed(M + F_)
+    x = (torch.randn(M, K, generator=g)).to(dtype).cuda()
+    W1 = (torch.randn(F_, K, generator=g) * K ** -0.5).to(dtype).cuda()
+    b1 = (torch.randn(F_, generator=g) * 0.3).to(dtype).cuda()
+    W2 = (torch.randn(K, F_, generator=g) * F_ ** -0.5).to(dtype).cuda()
+    b2 = (torch.randn(K, generator=g) * 0.3).to(dtype).cuda()
+    w = torch.randn(M, K, generator=g).to(dtype).cuda()
+    grads = []
+    for folded in (False, True):
+        ps = [t.detach().clone().requires_grad_() for t in (x, W1, b1, W2, b2)]
+        h = ops.linear(ps[0], ps[1], ps[2], act="relu", bwd_premasked=folded)
+        y = ops.linear(h, ps[3], ps[4], mask_dx=folded)
+        (y * w).sum().backward()
+        grads.append([y.detach()] + [p.grad for p in ps])
+    t = 1e-5 if dtype == torch.float32 else 1e-2
+    for a, b, name in zip(grads[0], grads[1], ["y", "dx", "dW1", "db1", "dW2", "db2"]):
+        assert_close(b.float(), a.float(), t, name)
+
+
 def test_linear_a_is_identity_asymmetric():
     """Transpose-detecting check: W = asymmetric matrix, x = identity."""
     from mmgl_amd import ops

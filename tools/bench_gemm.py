@@ -23,7 +23,7 @@ def run(M, N, K, act=0, dtype=torch.bfloat16, iters=30):
     ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
     st = stream_ptr()
     f = lambda: L.mmgl_linear_fwd(ptr(x), ptr(W), ptr(b), ptr(y), M, N, K, act, 1.0, code, st)
-    g = lambda: L.mmgl_linear_bwd(ptr(dy), ptr(y), ptr(x), ptr(W), ptr(dx), ptr(dW), ptr(db), ptr(ws), nws, M, N, K, act, 1.0, 0, code, st)
+    g = lambda: L.mmgl_linear_bwd(ptr(dy), ptr(y), ptr(x), ptr(W), ptr(dx), ptr(dW), ptr(db), ptr(ws), nws, M, N, K, act, 1.0, 0, 0, code, st)
     for _ in range(3):
         assert f() == 0 and g() == 0
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
