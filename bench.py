@@ -312,6 +312,17 @@ def main():
                 gb = alg_b / (xb["ms_avg"] * 1e-3) / 1e9
                 kern["mmgl_xattn_bwd"].update(bound="hbm", gbs=round(gb, 1), frac=round(gb / HBM_PEAK_GBS, 4))
             line["kernels"] = kern
+            # BASELINE.json's second metric, "cross-attn TFLOPS % of peak": every mmgl_linear_* call of this step belongs to the
+            # gated cross-attention layers (projections + FFN; the frozen layers' GEMMs are library calls), so the layer-level
+            # rate is (their FLOPs + the attention core's) / (their time + the core's time), forward and backward.
+            lf, lb_, xf, xb2 = (ks.get(n) for n in ("mmgl_linear_fwd", "mmgl_linear_bwd", "mmgl_xattn_fwd", "mmgl_xattn_bwd"))
+            if lf and lb_ and xf and xb2:
+                core_f = sum(4.0 * T * sv * d for sv in valid_keys) * xf["calls"]
+                fwd_tf = (lf["flops"] + core_f) / ((lf["ms_total"] + xf["ms_total"]) * 1e-3) / 1e12
+                bwd_tf = (lb_["flops"] + 2.0 * core_f) / ((lb_["ms_total"] + xb2["ms_total"]) * 1e-3) / 1e12
+                line["cross_attention_layers"] = {"fwd_tflops": round(fwd_tf, 1), "fwd_frac_of_peak": round(fwd_tf / peak_tf, 4),
+                                                  "bwd_tflops": round(bwd_tf, 1), "bwd_frac_of_peak": round(bwd_tf / peak_tf, 4),
+                                                  "peak_tflops": peak_tf, "scope": "GEMMs + attention core of the 4 gated cross-attention layers"}
             line["kernels_note"] = f"per C-ABI entry point over {table_steps} extra steps after the timed region"
             line["hip_path_ms_per_step"] = round(sum(s["ms_total"] for s in ks.values()) / table_steps, 2)
         if world == 1 and not args.no_cpu_baseline:
