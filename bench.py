@@ -113,7 +113,11 @@ def synthetic_batch(B, cfg, seed, device, Lin=512, Lout=128, Ln=512, vocab=50272
                  neighbor_pos_ids=npos, text_locations=tloc, neighbor_images=imgs, neighbor_images_pos_ids=ipos,
                  image_locations=iloc)
     valid_keys = [(int((npos[b] > 0).sum()) + int((ipos[b] > 0).sum())) * 4 for b in range(B)]
-    return {k: v.to(device) for k, v in batch.items()}, valid_keys
+    from mmgl_amd.model.modelling_cross_attention import host_metadata
+    meta = host_metadata(batch)                      # what the trainer reads off the collated batch before the H2D copy
+    batch = {k: v.to(device) for k, v in batch.items()}
+    batch["host_meta"] = meta
+    return batch, valid_keys
 
 
 def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1):
@@ -131,7 +135,7 @@ def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1):
         sd[k].requires_grad_()
     text_model = model.text_model.float().cpu()
     visual_model = model.visual_model.float().cpu()
-    b = {k: v[:n_samples].cpu() for k, v in batch.items()}
+    b = {k: v[:n_samples].cpu() for k, v in batch.items() if k != "host_meta"}
     ocfg = lm_ref.LMConfig(vocab_size=lm_cfg.vocab_size, hidden_size=lm_cfg.hidden_size, num_attention_heads=lm_cfg.num_attention_heads,
                            ffn_dim=lm_cfg.ffn_dim, num_hidden_layers=lm_cfg.num_hidden_layers,
                            word_embed_proj_dim=lm_cfg.word_embed_proj_dim, neighbor_layer_wise=cfg["wise"])
@@ -180,11 +184,23 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=2)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched bare (`python bench.py --gpus N`): spawn the N ranks ourselves, one process per GPU, the way the reference
+        # does with mp.spawn (language_modelling/run_generation.py:265-266); the re-executed ranks land in the branch below
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` or torchrun --nproc-per-node N")
     ndev = torch.cuda.device_count()
     backend = os.environ.get("MMGL_DIST_BACKEND", "nccl")        # "gloo": dry run of the N-rank path on fewer GPUs than ranks
     if backend == "nccl" and local_rank >= ndev:
@@ -267,6 +283,44 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # ---- gradient-exchange report (outside the timed region; every rank runs the same collectives)
+    exchange = None
+    if world > 1:
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                                         # = number of ranks RCCL actually connected
+        ex_steps = max(1, args.warmup + args.steps + table_steps)
+        bytes_per_step = engine.exchange_bytes / ex_steps
+
+        def timed(fn, n):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t) / n], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        def bare_exchange():                                          # the same bucket all-reduces with nothing to overlap with
+            for b in engine.buckets:
+                dist.all_reduce(engine.flat_grad[b["start"]:b["end"]])
+        bare_exchange()
+        ar_s = timed(bare_exchange, 3)
+        engine.sync = False                                           # the same step without the exchange
+        step()
+        nosync_s = timed(step, 3)
+        engine.sync = True
+        step_s = dt / args.steps
+        exposed = max(0.0, step_s - nosync_s)
+        exchange = {"rccl_ranks": int(ones.item()), "backend": backend, "buckets": len(engine.buckets),
+                    "exchange_bytes_per_step_per_gpu": int(bytes_per_step),
+                    "wire_bytes_per_step_per_gpu": int(2 * (world - 1) / world * bytes_per_step),
+                    "allreduce_ms_alone": round(ar_s * 1e3, 3), "step_ms_without_exchange": round(nosync_s * 1e3, 3),
+                    "exposed_ms": round(exposed * 1e3, 3),
+                    "overlap_fraction": round(1.0 - min(1.0, exposed / ar_s), 4) if ar_s > 0 else None,
+                    "algbw_GBps": round(bytes_per_step / ar_s / 1e9, 1) if ar_s > 0 else None}
+
     if rank == 0:
         value = world * args.batch * args.steps / dt
         line = {
@@ -325,6 +379,8 @@ def main():
                                                   "peak_tflops": peak_tf, "scope": "GEMMs + attention core of the 4 gated cross-attention layers"}
             line["kernels_note"] = f"per C-ABI entry point over {table_steps} extra steps after the timed region"
             line["hip_path_ms_per_step"] = round(sum(s["ms_total"] for s in ks.values()) / table_steps, 2)
+        if exchange is not None:
+            line["exchange"] = exchange
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, cfg, lm_cfg, batch, args.cpu_samples)
         print(json.dumps(line), flush=True)

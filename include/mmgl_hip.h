@@ -227,6 +227,22 @@ int mmgl_adamw_step(void* param, float* master, const void* grad, float* exp_avg
  *   dx = dres * keep / (1 - p).  dgamma/dbeta fp32 optional (workspace as for mmgl_layernorm_bwd).
  * mmgl_activation_fwd: y = act(x) elementwise, in place allowed; act 1 relu, 2 gelu (erf), 3 quick_gelu, 4 gelu (tanh).
  */
+/* General NT GEMM with fused epilogue (the frozen path's linears, their dgrads, lm_head, the encoder linears):
+ *   y[M,N] = act( (x[M,K] @ W[N,K]^T + bias[N]) * out_scale )   then   y = (zmask > 0 ? y : 0)   then   y += residual
+ * replaces: nn.Linear inside the frozen MPTDecoderLayer / MPTAttention (model/modelling_cross_attention.py:194-199, :273,
+ *           :352-355), lm_head (:826), the RobertaModel / CLIPVisionModel linears behind :992 / :1018, and autograd's
+ *           dgrad of each of them (dx = dy @ W  ==  an NT GEMM against the cached W^T; zmask = the ReLU output whose
+ *           backward is folded into the epilogue).
+ *   bias [N], residual [M,N], zmask [M,N] may be NULL; act: 0 none, 1 relu, 2 gelu (erf), 3 quick_gelu, 4 gelu (tanh).
+ * bf16 shapes with K % 128 == 0, K >= 256, N % 16 == 0 and enough 256x256 tiles run on the persistent ping-pong kernel
+ * (gemm8p.hip; mmgl_gemm_nt_fast reports that); anything else is composed from mmgl_linear_fwd + the elementwise kernels.
+ * ldx / ldw / ldy: row strides in elements (residual and zmask share ldy); the composed path needs dense operands.
+ * mmgl_relu_bwd: out = dy * (y > 0), the backward of a stand-alone ReLU epilogue (in place allowed). */
+int mmgl_gemm_nt_fast(int M, int N, int K, int ldx, int ldw, int ldy, int dtype);
+int mmgl_gemm_nt(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, const void* zmask,
+                 void* y, int ldy, int M, int N, int K, int act, float out_scale, int dtype, void* stream);
+int mmgl_relu_bwd(const void* dy, const void* y, void* out, size_t n, int dtype, void* stream);
+
 int mmgl_encattn_fwd(const void* q, const void* k, const void* v, const int32_t* cu_seqlens, void* out, int nseq,
                      int H, int D, int ld_in, int ld_out, int max_len, int q_rows, int dtype, void* stream);
 int mmgl_add_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* sum_out,

@@ -58,6 +58,9 @@ SIGNATURES = {
     "mmgl_add_layernorm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, F, F, U, I, P]),
     "mmgl_add_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, F, U, I, P]),
     "mmgl_activation_fwd": (I, [P, P, Z, I, I, P]),
+    "mmgl_gemm_nt_fast": (I, [I, I, I, I, I, I, I]),
+    "mmgl_gemm_nt": (I, [P, I, P, I, P, P, P, P, I, I, I, I, I, F, I, P]),
+    "mmgl_relu_bwd": (I, [P, P, P, Z, I, P]),
 }
 
 _lib = None

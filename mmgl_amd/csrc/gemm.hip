@@ -14,6 +14,7 @@
 // dgrad / wgrad are the same kernel on explicitly transposed operands (tile transpose kernel below); the ReLU
 // mask, the out_scale and the bias column-sum are fused into that transpose / mask pass.
 #include "common.h"
+#include "gemm8p.h"
 #include <stdlib.h>
 
 namespace {
@@ -308,6 +309,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const bf16* __restri
 // tiles to fill the chip twice (below that the 128x128 kernel's finer tiling wins)
 inline bool big_tile_shape(int M, int N, int K) { return K % 64 == 0 && (size_t)cdiv(M, 256) * cdiv(N, 256) >= 512; }
 
+inline int tune_gemm_8p() {
+    static const int v = [] { const char* e = getenv("MMGL_GEMM_8P"); return e ? atoi(e) : 1; }();
+    return v;
+}
+inline int tune_gemm_8p_min_tiles() {
+    static const int v = [] { const char* e = getenv("MMGL_GEMM_8P_MIN_TILES"); return e ? atoi(e) : 160; }();
+    return v;
+}
+
 inline int tune_gemm_big() {
     static const int v = [] { const char* e = getenv("MMGL_GEMM_BIG"); return e ? atoi(e) : 1; }();
     return v;
@@ -386,6 +396,11 @@ int launch_gemm(const T* X, const T* W, T* Y, const T* bias, int M, int N, int K
     if (K % VN || N % 4 || (X2 && K2 % VN))
         MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm: K (%d) must be a multiple of %d and N (%d) of 4", K, VN, N);
     if constexpr (sizeof(T) == 2) {
+        // persistent ping-pong kernel (gemm8p.hip) whenever the shape gives it enough 256x256 tiles
+        if (!X2 && !accumulate && tune_gemm_8p() && gemm8p_supported(M, N, K, K, K, N) && cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles()) {
+            if (zmask_done) *zmask_done = zmask != nullptr;
+            return launch_gemm8p((const bf16*)X, K, (const bf16*)W, K, (bf16*)Y, N, (const bf16*)bias, nullptr, (const bf16*)zmask, M, N, K, act, scale, st);
+        }
         // big-tile kernel when the shape fills the chip with 256x256 tiles (>= 2 tiles per CU keeps the tail small)
         if (!X2 && tune_gemm_big() && big_tile_shape(M, N, K)) {
             const int tm = cdiv(M, BT), tn = cdiv(N, BT);
@@ -1174,4 +1189,51 @@ extern "C" int mmgl_transpose(const void* in, void* out, int R, int C, int dtype
     hipStream_t st = (hipStream_t)stream;
     DT_SWITCH("mmgl_transpose", launch_transpose<bf16>((const bf16*)in, nullptr, (bf16*)out, nullptr, R, C, 1.f, 0, st),
               launch_transpose<float>((const float*)in, nullptr, (float*)out, nullptr, R, C, 1.f, 0, st));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// General NT GEMM with a fused epilogue (the frozen path's linears and their dgrads): fast path = gemm8p.hip; every other
+// shape / dtype is composed from the kernels above plus the elementwise entry points.
+extern "C" int mmgl_activation_fwd(const void* x, void* y, size_t n, int act, int dtype, void* stream);
+extern "C" int mmgl_gated_residual_fwd(const void* residual, const void* x, const float* gate, void* y, size_t n, float p_drop,
+                                       uint64_t seed, int dtype, void* stream);
+
+extern "C" int mmgl_gemm_nt_fast(int M, int N, int K, int ldx, int ldw, int ldy, int dtype) {
+    return dtype == MMGL_BF16 && tune_gemm_8p() && gemm8p_supported(M, N, K, ldx, ldw, ldy) &&
+           cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles();
+}
+
+extern "C" int mmgl_gemm_nt(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, const void* zmask,
+                            void* y, int ldy, int M, int N, int K, int act, float out_scale, int dtype, void* stream) {
+    MMGL_CHECK_ARG(x && W && y, "mmgl_gemm_nt: null pointer");
+    MMGL_CHECK_ARG(act >= 0 && act <= 4, "mmgl_gemm_nt: unknown activation %d", act);
+    // K may exceed x's row length by less than one 128-wide K step when the matching columns of W are zero padding (the
+    // contraction over a vocabulary that is no multiple of 128): the tail of a row then reads the head of the next one
+    MMGL_CHECK_ARG(ldx + 127 >= K && ldw >= K && ldy >= N, "mmgl_gemm_nt: leading dimensions (%d, %d, %d) smaller than the rows (K=%d, N=%d)", ldx, ldw, ldy, K, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (mmgl_gemm_nt_fast(M, N, K, ldx, ldw, ldy, dtype))
+        return launch_gemm8p((const bf16*)x, ldx, (const bf16*)W, ldw, (bf16*)y, ldy, (const bf16*)bias, (const bf16*)residual,
+                             (const bf16*)zmask, M, N, K, act, out_scale, st);
+    if (ldx != K || ldw != K || ldy != N)
+        MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "mmgl_gemm_nt: strided operands (ld %d %d %d) need the bf16 fast path (K %% 128 == 0, N %% 16 == 0, "
+                  ">= %d tiles of 256x256); got M=%d N=%d K=%d dtype=%d", ldx, ldw, ldy, tune_gemm_8p_min_tiles(), M, N, K, dtype);
+    int rc = mmgl_linear_fwd(x, W, bias, y, M, N, K, act <= 1 ? act : 0, out_scale, dtype, stream);
+    if (rc) return rc;
+    const size_t n = (size_t)M * N;
+    if (act >= 2 && (rc = mmgl_activation_fwd(y, y, n, act, dtype, stream))) return rc;
+    if (zmask) {
+        if (dtype == MMGL_BF16) rc = launch_relu_mask<bf16>((const bf16*)y, (const bf16*)zmask, (bf16*)y, n, 1.f, st);
+        else rc = launch_relu_mask<float>((const float*)y, (const float*)zmask, (float*)y, n, 1.f, st);
+        if (rc) return rc;
+    }
+    if (residual) rc = mmgl_gated_residual_fwd(residual, y, nullptr, y, n, 0.f, 0, dtype, stream);
+    return rc;
+}
+
+/* dy * (y > 0): backward of a stand-alone ReLU (in place allowed) */
+extern "C" int mmgl_relu_bwd(const void* dy, const void* y, void* out, size_t n, int dtype, void* stream) {
+    MMGL_CHECK_ARG(dy && y && out, "mmgl_relu_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    DT_SWITCH("mmgl_relu_bwd", launch_relu_mask<bf16>((const bf16*)dy, (const bf16*)y, (bf16*)out, n, 1.f, st),
+              launch_relu_mask<float>((const float*)dy, (const float*)y, (float*)out, n, 1.f, st));
 }

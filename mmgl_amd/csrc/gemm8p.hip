@@ -1,0 +1,350 @@
+// Persistent 256x256 "ping-pong" NT GEMM for gfx950 (bf16):   Y[M,N] = epi( X[M,K] . W[N,K]^T )
+// replaces: every nn.Linear of the frozen path of reference model/modelling_cross_attention.py -- q/k/v/out_proj of the
+//           frozen decoder layers (:194-199, :273), fc1+ReLU / fc2 (:352-355), lm_head (:826), the RoBERTa / CLIP encoder
+//           linears behind :992 / :1018 -- and their dgrads (dx = dy . W as an NT GEMM against W^T).
+//
+// Structure (one workgroup = 8 waves = one CU, persistent over output tiles):
+//   * wave (wr, wc) = (wave >> 2, wave & 3) owns a 128 (m) x 64 (n) block of the 256x256 tile: 128 fp32 accumulator VGPRs.
+//     W is the MFMA A operand with its 16 fragment rows mapped to n = 16 g' + 4 t + r  (a free row permutation in the
+//     fragment addressing), so a lane ends up with 16 CONSECUTIVE output columns of one output row: 2 x 16-byte stores,
+//     bias / activation / residual without cross-lane traffic.
+//   * the two waves that share a SIMD (w and w + 4) run half a phase apart: a phase is  [ds_read fragments | issue LDS-DMA |
+//     s_waitcnt vmcnt(N)] s_barrier [16 MFMA] s_barrier ; waves 4-7 take one extra barrier up front, so while one wave of
+//     a SIMD is in its MFMA cluster the other one is in its memory cluster (and the matrix pipe never waits for LDS).
+//   * operands stream global -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane) in UNITS of 128 LDS rows x 128 B
+//     (64 bf16 of K) = 16 KiB, the exact set of rows ONE phase reads: Xa (rows 0-63 of each wave's m block), Wb (fragment
+//     rows t = 2,3), Xb (rows 64-127), Wa (t = 0,1 of the NEXT K tile: read one phase early into the W register set the
+//     finished Wb just freed, so every phase reads 8 / 4 / 8 / 4 fragments and no phase is LDS-bound).  8 unit slots of LDS
+//     (128 KiB) form a ring: the unit read in phase p sits in slot p & 7, was issued in phase p - 6 and waited for (counted
+//     vmcnt, never 0) in phase p - 1; its slot is re-issued in phase p + 2.  The stream of units runs across K tiles AND
+//     across output tiles: the first
+//     K tiles of the next output tile are in flight while the current tile finishes and stores, so there is no per-tile
+//     pipeline fill.  Rows are addressed through buffer descriptors rebuilt per tile (rows past M / N read as zero: no
+//     clamping, no branches), the K offset rides in the scalar offset: no vector address arithmetic in the loop.
+//   * LDS rows are 128 B with the 16-byte slot XOR-swizzled by (row >> 1) & 7 on the SOURCE side (an LDS-DMA destination is
+//     lane-linear): every ds_read_b128 of a fragment (16 consecutive rows, same k slot) is bank-conflict free.
+// Needs K % 128 == 0, K >= 256, N % 16 == 0.  Everything else goes to the 128x128 kernel of gemm.hip.
+#include "common.h"
+#include "gemm8p.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef unsigned p8_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int P8_UNIT = 16384;      // bytes per staged unit
+constexpr int P8_LDS = 8 * P8_UNIT;
+
+struct P8Args {
+    const bf16* X;
+    const bf16* W;
+    bf16* Y;
+    const bf16* bias;      // [N] or null
+    const bf16* resid;     // [M,N] or null: added after the activation
+    const bf16* zmask;     // [M,N] or null: output zeroed where zmask <= 0 (ReLU backward of the tensor this GEMM differentiates)
+    int M, N, K;
+    int ldx, ldw, ldy;     // row strides in elements (multiples of 8); resid and zmask share ldy
+    float scale;
+    int act;
+    int tiles_m, tiles_n, total;
+};
+
+// ACT is a compile-time family: 0 = none / ReLU (a clamp against `lo` = 0 or -inf, branch-free), 2 gelu (erf), 3 quick_gelu,
+// 4 gelu (tanh)
+template <int ACT> __device__ __forceinline__ float p8_act(float v, float lo) {
+    if constexpr (ACT == 2) {
+        // exact-GELU with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): ~14 VALU per value instead
+        // of libm's erff -- the epilogue runs beside the partner wave's MFMAs and must stay short
+        const float z = fabsf(v) * 0.70710678118654752f;
+        const float t = __frcp_rn(1.f + 0.3275911f * z);
+        const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+        const float er = 1.f - poly * __expf(-z * z);
+        return 0.5f * v * (1.f + copysignf(er, v));
+    }
+    else if constexpr (ACT == 3) return v / (1.f + __expf(-1.702f * v));
+    else if constexpr (ACT == 4) {
+        const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+        return 0.5f * v * (1.f + tanhf(u));
+    } else return fmaxf(v, lo);
+}
+
+// lane id from the exec mask (v_mbcnt): recomputed where it is needed instead of keeping a register (or, under this kernel's
+// register pressure, a scratch slot and its vmcnt(0) reload) alive across the main loop
+__device__ __forceinline__ int p8_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+#define P8_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define P8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define P8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel(P8Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int x = lane & 15, g = lane >> 4;
+    const int K = a.K, nk = K >> 6;
+
+    // ---- persistent tile schedule: in every round of gridDim.x tiles, XCD j (blocks b % 8 == j) takes 32 consecutive
+    // virtual ids = one 8 x 4 group of tiles (grouped_tile): activation K slices are shared by 4 workgroups of one L2
+    const int G = gridDim.x;
+    const int wg = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    auto tile_origin = [&](int it, int& m0, int& n0) -> bool {
+        const int v = it * G + wg;
+        if (v >= a.total) return false;
+        int tm, tn;
+        grouped_tile(v, a.tiles_m, a.tiles_n, tm, tn);
+        m0 = tm * 256;
+        n0 = tn * 256;
+        return true;
+    };
+    // rows [row0, rows) of an operand with row stride ld: everything past the last row reads as zero.  (A K tile may run past
+    // the end of a ROW when the caller pads K -- lm_head's dgrad contracts over V = 50272 -- and then reads the start of the next
+    // row: finite values that meet the zero padding of the other operand.)
+    auto mk_desc = [&](const bf16* base, int row0, int rows, int ld, bool valid) {
+        long long rem = valid ? (long long)(rows - row0) * ld * 2 : 0;
+        if (rem > 0xffffffffLL) rem = 0xffffffffLL;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (valid ? (size_t)row0 * ld : 0)), 0, (int)(unsigned)rem, 0x00020000);
+    };
+
+    // ---- staging offsets: unit type 0 Xa, 1 Wb, 2 Xb, 3 Wa; each wave moves pieces `wave` and `wave + 8` (8 LDS rows each)
+    int voff[4][2];
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = (wave + 8 * i) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((lr >> 1) & 7);
+            int srow;
+            if (!(ty & 1)) srow = (lr >> 6) * 128 + (ty == 2 ? 64 : 0) + (lr & 63);
+            else {
+                const int u = ty == 1 ? 1 : 0, tt = (lr >> 4) & 1, xp = lr & 15;
+                srow = (lr >> 5) * 64 + 16 * (xp >> 2) + 4 * (2 * u + tt) + (xp & 3);
+            }
+            voff[ty][i] = srow * ((ty & 1) ? a.ldw : a.ldx) * 2 + c * 16;
+        }
+    auto stage = [&](int ty, int slot, __amdgpu_buffer_rsrc_t rs, int kbyte) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + slot * P8_UNIT + (wave + 8 * i) * 1024), 16, voff[ty][i],
+                                                     kbyte, 0, 0);
+    };
+
+    // ---- fragment addressing: row x of a 16-row block, k slot (ks * 4 + g) ^ key
+    const int s0 = g ^ ((x >> 1) & 7);
+    const int o0 = x * 128 + (s0 << 4), o1 = x * 128 + ((s0 ^ 4) << 4);
+    const char* bx0 = smem + wr * 8192 + o0;
+    const char* bx1 = smem + wr * 8192 + o1;
+    const char* bw0 = smem + wc * 4096 + o0;
+    const char* bw1 = smem + wc * 4096 + o1;
+    auto rdX = [&](bf16x8 (&f)[2][4], int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[0][j] = *(const bf16x8*)(bx0 + slot * P8_UNIT + j * 2048);
+            f[1][j] = *(const bf16x8*)(bx1 + slot * P8_UNIT + j * 2048);
+        }
+    };
+    auto rdW = [&](bf16x8 (&f)[2][2], int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f[0][t] = *(const bf16x8*)(bw0 + slot * P8_UNIT + t * 2048);
+            f[1][t] = *(const bf16x8*)(bw1 + slot * P8_UNIT + t * 2048);
+        }
+    };
+
+    f32x4 acc[4][8];
+
+#define P8_MM(FX, FW, J0, T0)                                                                  \
+    do {                                                                                       \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                    \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                   \
+                _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                               \
+                    mma16(acc[(T0) + t_][(J0) + j_], FW[ks_][t_], FX[ks_][j_]);                \
+    } while (0)
+
+    int m0 = 0, n0 = 0, m1 = 0, n1 = 0;
+    int it = 0;
+    if (!tile_origin(0, m0, n0)) return;
+    bool have_next = tile_origin(1, m1, n1);
+    __amdgpu_buffer_rsrc_t dXc = mk_desc(a.X, m0, a.M, a.ldx, true), dWc = mk_desc(a.W, n0, a.N, a.ldw, true);
+    __amdgpu_buffer_rsrc_t dXn = mk_desc(a.X, m1, a.M, a.ldx, have_next), dWn = mk_desc(a.W, n1, a.N, a.ldw, have_next);
+
+    // ---- epilogue plumbing.  Lane (x, g) owns, for each of its 8 rows m = m0 + wr*128 + 16 J + x, the 16 columns
+    // n = n0 + wc*64 + 16 g + (4 t + r).  The lane's 16 bias values are fetched at the top of the tile's last K-tile pair, five
+    // phases before their first use, so that the wait for them is a counted vmcnt behind younger LDS-DMA loads, not a drain.
+    // Output rows go through a buffer descriptor based at row m0 (rows past M and, via an all-ones offset, columns past N are
+    // dropped by the hardware: no branches around the stores).
+    bf16x8 braw0, braw1;
+    // through a descriptor over bias[0..N) (empty without a bias): columns past N and the no-bias case read as zero, branch-free
+    const __amdgpu_buffer_rsrc_t dBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 2 : 0, 0x00020000);
+    auto fetch_bias = [&](int nt0) __attribute__((always_inline)) {
+        const int nb = nt0 + wc * 64 + 16 * (p8_lane() >> 4);
+        braw0 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dBias, nb * 2, 0, 0));
+        braw1 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dBias, nb * 2 + 16, 0, 0));
+    };
+    auto zero_acc = [&](int J0, int T0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[T0][J0 + j] = vzero<f32x4>(); acc[T0 + 1][J0 + j] = vzero<f32x4>(); }
+    };
+    auto y_desc = [&](const bf16* base, int mt0) {
+        long long rem = (long long)(a.M - mt0) * a.ldy * 2;
+        if (rem > 0xffffffffLL) rem = 0xffffffffLL;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)mt0 * a.ldy), 0, (int)(unsigned)rem, 0x00020000);
+    };
+    const float relu_lo = a.act == 1 ? 0.f : -3.0e38f;
+    // epilogue of one quadrant (rows J0..J0+3 x fragment rows T0, T0+1 = 8 consecutive columns per lane): 4 x 16-byte stores
+    auto epi = [&](int J0, int T0) __attribute__((always_inline)) {
+        const int ln = p8_lane();
+        const int ncol_l = wc * 64 + 16 * (ln >> 4);         // column of this lane inside the tile
+        const bool ncol = n0 + ncol_l < a.N;
+        const unsigned vo = ncol ? (unsigned)(((wr * 128 + (ln & 15)) * a.ldy + n0 + ncol_l + 4 * T0) * 2) : 0xffffffffu;
+        __amdgpu_buffer_rsrc_t dY = y_desc(a.Y, m0);
+        const bf16x8 br = T0 ? braw1 : braw0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned off = ncol ? vo + (unsigned)((J0 + j) * 16 * a.ldy * 2) : 0xffffffffu;
+            const f32x4 lo = acc[T0][J0 + j], hi = acc[T0 + 1][J0 + j];
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] + (float)br[e]) * a.scale;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = p8_act<ACT>(v[e], relu_lo);
+            if constexpr (ZR) {
+                if (a.zmask) {
+                    __amdgpu_buffer_rsrc_t dZ = y_desc(a.zmask, m0);
+                    const bf16x8 z = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dZ, off, 0, 0));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ((float)z[e] > 0.f) ? v[e] : 0.f;
+                }
+                if (a.resid) {
+                    __amdgpu_buffer_rsrc_t dR = y_desc(a.resid, m0);
+                    const bf16x8 rr = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dR, off, 0, 0));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
+                }
+            }
+            f32x8 o8 = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+            const bf16x8 ob = __builtin_convertvector(o8, bf16x8);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, ob), dY, off, 0, 0);
+        }
+        zero_acc(J0, T0);
+    };
+
+    // ---- prologue: units -1 .. 5 of the stream  (Wa(0) | Xa(0) Wb(0) Xb(0) Wa(1) | Xa(1) Wb(1))
+    stage(3, 7, dWc, 0);
+    stage(0, 0, dXc, 0);
+    stage(1, 1, dWc, 0);
+    stage(2, 2, dXc, 0);
+    stage(3, 3, dWc, 128);
+    stage(0, 4, dXc, 128);
+    stage(1, 5, dWc, 128);
+    zero_acc(0, 0); zero_acc(0, 2); zero_acc(4, 0); zero_acc(4, 2);
+    // two W fragment sets that swap roles every K tile: even K tiles keep Wa in fwA and Wb in fwB, odd ones Wa in fwB, Wb in fwA
+    bf16x8 fx[2][4], fwA[2][2], fwB[2][2];
+    P8_VMCNT(10);                        // units -1 and 0 have landed
+    P8_BARRIER();
+    rdW(fwA, 7);
+    P8_LGKM0();
+    if (wr) P8_BARRIER();                // waves 4-7 run half a phase behind waves 0-3
+
+    // One phase.  READ: this phase's fragments.  (TY, SLOT, DK): the unit staged now = the one read 6 phases from now, of
+    // K tile kt + DK (past the end of this output tile: K tile kt + DK - nk of the next one).  vmcnt(10): the 5 younger units
+    // may stay in flight.  MMA: the 16 MFMAs.  The memory cluster is the critical path of the ping-pong (two LDS-DMA issues and
+    // up to 8 ds_reads against the partner's 16 MFMAs): nothing else lives in this loop -- no branch, no address arithmetic.
+#define P8_PHASE(READ, TY, SLOT, DK, MMA)                                                        \
+    do {                                                                                         \
+        READ;                                                                                    \
+        {                                                                                        \
+            const int kk_ = kt + (DK);                                                           \
+            const bool nx_ = kk_ >= nk;                                                          \
+            const int kb_ = (nx_ ? kk_ - nk : kk_) * 128;                                        \
+            if ((TY) & 1) stage((TY), (SLOT), nx_ ? dWn : dWc, kb_);                             \
+            else stage((TY), (SLOT), nx_ ? dXn : dXc, kb_);                                      \
+        }                                                                                        \
+        P8_VMCNT(10);                                                                            \
+        P8_BARRIER();                                                                            \
+        P8_LGKM0();                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                           \
+        MMA;                                                                                     \
+        __builtin_amdgcn_s_setprio(0);                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        P8_BARRIER();                                                                            \
+    } while (0)
+
+    for (;;) {
+        // the lane's 16 bias values for this tile: fetched now, consumed by the epilogue a whole tile later (the wait for them
+        // is a counted vmcnt behind many younger loads, never a drain of the LDS-DMA stream)
+        fetch_bias(n0);
+        for (int kt = 0; kt < nk; kt += 2) {
+            P8_PHASE(rdX(fx, 0), 2, 6, 1, P8_MM(fx, fwA, 0, 0));
+            P8_PHASE(rdW(fwB, 1), 3, 7, 2, P8_MM(fx, fwB, 0, 2));
+            P8_PHASE(rdX(fx, 2), 0, 0, 2, P8_MM(fx, fwB, 4, 2));
+            P8_PHASE(rdW(fwB, 3), 1, 1, 2, P8_MM(fx, fwA, 4, 0));
+            P8_PHASE(rdX(fx, 4), 2, 2, 2, P8_MM(fx, fwB, 0, 0));
+            P8_PHASE(rdW(fwA, 5), 3, 3, 3, P8_MM(fx, fwA, 0, 2));
+            P8_PHASE(rdX(fx, 6), 0, 4, 3, P8_MM(fx, fwA, 4, 2));
+            P8_PHASE(rdW(fwA, 7), 1, 5, 3, P8_MM(fx, fwB, 4, 0));
+        }
+        // epilogue of tile (m0, n0), beside the partner wave's MFMAs (waves 0-3 and 4-7 reach it half a phase apart)
+        epi(0, 0);
+        epi(0, 2);
+        epi(4, 2);
+        epi(4, 0);
+        if (!have_next) break;
+        ++it;
+        m0 = m1;
+        n0 = n1;
+        dXc = dXn;
+        dWc = dWn;
+        have_next = tile_origin(it + 1, m1, n1);
+        dXn = mk_desc(a.X, m1, a.M, a.ldx, have_next);
+        dWn = mk_desc(a.W, n1, a.N, a.ldw, have_next);
+    }
+    P8_VMCNT(0);                         // no LDS-DMA may outlive the workgroup
+    if (!wr) P8_BARRIER();               // balance the stagger barrier
+}
+
+}  // namespace
+
+bool gemm8p_supported(int M, int N, int K, int ldx, int ldw, int ldy) {
+    return M > 0 && N > 0 && K >= 256 && K % 128 == 0 && N % 16 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0 &&
+           (long long)M * ldx * 2 < 0xffffffffLL && (long long)N * ldw * 2 < 0xffffffffLL;
+}
+
+int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, const bf16* resid,
+                  const bf16* zmask, int M, int N, int K, int act, float scale, hipStream_t st) {
+    if (!gemm8p_supported(M, N, K, ldx, ldw, ldy))
+        MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm8p: shape M=%d N=%d K=%d (ld %d %d %d) not supported", M, N, K, ldx, ldw, ldy);
+    P8Args a;
+    a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.resid = resid; a.zmask = zmask;
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.scale = scale; a.act = act;
+    a.tiles_m = cdiv(M, 256); a.tiles_n = cdiv(N, 256); a.total = a.tiles_m * a.tiles_n;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess)
+            MMGL_FAIL(MMGL_ERR_HIP, "gemm8p: hipGetDeviceProperties failed");
+        n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+        const void* ks[6] = {(const void*)gemm8p_kernel<0, false>, (const void*)gemm8p_kernel<0, true>, (const void*)gemm8p_kernel<2, false>,
+                             (const void*)gemm8p_kernel<3, false>, (const void*)gemm8p_kernel<3, true>, (const void*)gemm8p_kernel<4, true>};
+        for (const void* kf : ks) {
+            hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+            if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+    }
+    const int grid = a.total < n_cu ? a.total : n_cu;
+    const bool zr = resid || zmask;
+#define P8_LAUNCH(A, Z) hipLaunchKernelGGL((gemm8p_kernel<A, Z>), dim3(grid), dim3(512), P8_LDS, st, a)
+    switch (act) {
+        case 0: case 1: if (zr) P8_LAUNCH(0, true); else P8_LAUNCH(0, false); break;
+        case 2: if (zr) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm8p: gelu(erf) with residual / zmask is not instantiated"); P8_LAUNCH(2, false); break;
+        case 3: if (zr) P8_LAUNCH(3, true); else P8_LAUNCH(3, false); break;
+        case 4: P8_LAUNCH(4, true); break;
+        default: MMGL_FAIL(MMGL_ERR_INVALID, "gemm8p: unknown activation %d", act);
+    }
+#undef P8_LAUNCH
+    MMGL_CHECK_LAUNCH("gemm8p");
+    return MMGL_OK;
+}

@@ -189,26 +189,55 @@ class DataParallelEngine:
         return self.flat_grad.float().norm() / self.world
 
     # ---------------------------------------------------------------------------------- checkpointing
+    def _model_param_names(self):
+        """Names in `model.parameters()` order -- the index space of the reference's torch.optim.AdamW(model.parameters())
+        (run_generation.py:328): tied parameters appear once, frozen ones are counted."""
+        return [n for n, _ in self.model.named_parameters()]
+
     def state_dict(self):
-        """Same layout as torch.optim.AdamW.state_dict() over self.params in order (reference ckpt 'optimizer', :411)."""
+        """torch.optim.AdamW.state_dict() layout over ALL of model.parameters() in model order (reference ckpt 'optimizer',
+        :411): `state` holds the entries of the trainable parameters at their model index (frozen parameters never get state
+        in torch either), `param_groups[0]['params']` lists every index, so `torch.optim.AdamW(model.parameters())
+        .load_state_dict()` on the reference side accepts it.  `param_names` (index -> name) is an extra key torch ignores."""
+        names = self._model_param_names()
+        index = {n: i for i, n in enumerate(names)}
         state = {}
-        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
-            n = p.numel()
-            state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=self.exp_avg[o:o + n].view(p.shape).clone(),
-                            exp_avg_sq=self.exp_avg_sq[o:o + n].view(p.shape).clone())
-        group = dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, amsgrad=False,
-                     params=list(range(len(self.params))))
-        return dict(state=state, param_groups=[group], param_names=list(self.names))
+        for n, p, o in zip(self.names, self.params, self.offsets):
+            k = p.numel()
+            state[index[n]] = dict(step=torch.tensor(float(self.step_count)), exp_avg=self.exp_avg[o:o + k].view(p.shape).clone(),
+                                   exp_avg_sq=self.exp_avg_sq[o:o + k].view(p.shape).clone())
+        group = dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, amsgrad=False, maximize=False,
+                     foreach=None, capturable=False, differentiable=False, fused=None, params=list(range(len(names))))
+        return dict(state=state, param_groups=[group], param_names=names)
 
     def load_state_dict(self, sd):
-        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
-            st = sd["state"].get(i)
+        """Accepts this engine's checkpoints and the reference's (torch AdamW over model.parameters()): optimizer state is
+        matched BY PARAMETER NAME -- through the checkpoint's own `param_names` when present, else through this model's
+        named_parameters() order, which is the order the reference's optimizer indexed.  A checkpoint that carries state but
+        matches none of the trainable parameters is an error, never a silent cold start."""
+        names = sd.get("param_names") or self._model_param_names()
+        index = {n: i for i, n in enumerate(names)}
+        state = sd.get("state", {})
+        matched, missing = 0, []
+        for n, p, o in zip(self.names, self.params, self.offsets):
+            st = state.get(index[n]) if n in index else None
             if st is None:
+                missing.append(n)
                 continue
-            n = p.numel()
-            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
-            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            k = p.numel()
+            if st["exp_avg"].numel() != k:
+                raise ValueError(f"optimizer state of {n!r} has {st['exp_avg'].numel()} elements, the parameter has {k}")
+            self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
             self.step_count = int(st["step"])
+            matched += 1
+        if state and not matched:
+            raise ValueError("optimizer checkpoint carries state for none of the trainable parameters (index space mismatch): "
+                             f"checkpoint indices {sorted(state)[:5]}..., trainable names {self.names[:3]}...")
+        if missing and matched:
+            import warnings
+            warnings.warn(f"optimizer checkpoint has no state for {len(missing)} trainable parameter(s), e.g. {missing[:3]}: "
+                          "their Adam moments start from zero")
         g = sd["param_groups"][0]
         self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
         if self.master is not None:

@@ -106,7 +106,7 @@ class WarmupStepLR:
 
     def __init__(self, base_lr, warmup, step_size, gamma):
         self.base_lr, self.warmup, self.step_size, self.gamma = base_lr, max(int(warmup), 0), max(int(step_size), 1), gamma
-        self.last_step = 0
+        self.last_step = 0      # number of scheduler.step() calls so far: optimizer step n runs at lr_at(n - 1), as in the reference
 
     def lr_at(self, step):
         if self.warmup and step <= self.warmup:
@@ -124,7 +124,12 @@ class WarmupStepLR:
         return dict(last_step=self.last_step, base_lr=self.base_lr, warmup=self.warmup, step_size=self.step_size, gamma=self.gamma)
 
     def load_state_dict(self, sd):
-        self.last_step = sd.get("last_step", 0)
+        if "last_step" in sd:
+            self.last_step = sd["last_step"]
+        elif "last_epoch" in sd:              # torch / warmup_scheduler checkpoints of the reference count calls as last_epoch
+            self.last_step = sd["last_epoch"]
+        else:
+            raise ValueError(f"scheduler checkpoint has neither last_step nor last_epoch (keys: {sorted(sd)})")
 
 
 def corpus_bleu(preds, refs, n_gram=4):
@@ -243,6 +248,15 @@ def _summary_slices(args, logits, labels):
     return lg, lb
 
 
+def _host_meta(model, batch):
+    """Host-side facts about a collated batch (which neighbor slots are real, how long each neighbor text is) for models that
+    take them (`CrossAttentionModel.forward(host_meta=)`): the forward pass then never synchronises with the device."""
+    from ..model.modelling_cross_attention import CrossAttentionModel, host_metadata
+    if isinstance(model, CrossAttentionModel) and all(not v.is_cuda for v in batch.values()):
+        return {"host_meta": host_metadata(batch)}
+    return {}
+
+
 def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, run=None):
     """One epoch (reference :430-524).  `engine` = DataParallelEngine (replaces DDP + optimizer)."""
     from . import utils
@@ -263,11 +277,12 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
     end = time.time()
     for i, batch in enumerate(train_loader):
         data_time.update(time.time() - end)
+        extra = _host_meta(model, batch)               # read off the batch while it is still in host memory
         batch = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
         boundary = ((i + 1) % accum == 0) or (i == args.steps_per_epoch - 1)
         engine.sync = boundary                         # gradients cross xGMI once per optimizer step
         forward_start = time.time()
-        outputs = model(**batch)
+        outputs = model(**batch, **extra)
         _sync(device)
         forward_time.update(time.time() - forward_start)
         loss = outputs.loss
@@ -280,8 +295,11 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
         (loss / accum).backward()
         engine.finish_backward()
         if boundary:
-            lr = scheduler.step() if scheduler is not None else None
+            # reference order (:486-494): optimizer.step() at the current lr, THEN scheduler.step() -- the warm-up starts at 0
+            lr = scheduler.get_last_lr()[0] if scheduler is not None else None
             engine.step(lr)
+            if scheduler is not None:
+                scheduler.step()
             # the reference clips only if grad_clip > 2, AFTER the step, i.e. to no effect (:490-493): nothing to do
             engine.zero_grad()
             actual_step = (epoch * args.steps_per_epoch + i + 1) // accum
@@ -321,8 +339,9 @@ def evaluate_loop(val_loader, model, tokenizer, epoch, args, run=None, prefix="v
     with torch.no_grad():
         end = time.time()
         for i, batch in enumerate(val_loader):
+            extra = _host_meta(model, batch)
             batch = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
-            outputs = model(**batch)
+            outputs = model(**batch, **extra)
             logits = outputs.logits
             if args.decoder_only:
                 logits, labels = _summary_slices(args, logits, batch["labels"])
@@ -386,7 +405,9 @@ def save_checkpoint(path, model, engine, scheduler, epoch, acc1):
 
 
 def load_checkpoint(path, model, engine, scheduler, map_location):
-    ck = torch.load(path, map_location=map_location, weights_only=False)
+    # tensors + plain containers only: never unpickle arbitrary objects from a checkpoint file
+    with torch.serialization.safe_globals([OrderedDict]):
+        ck = torch.load(path, map_location=map_location, weights_only=True)
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ck["state_dict"].items()}
     model.load_state_dict(sd, strict=False)
     engine.sync_master_from_params()

@@ -7,20 +7,20 @@ parameters / state_dict keys; only their forward is replaced, for CUDA tensors, 
 
   * valid tokens of all neighbor sequences are concatenated ([ntok, hidden], `cu_seqlens`); no pad token is embedded,
     multiplied or attended to (dropping masked keys leaves every softmax unchanged: their weight is exactly 0);
-  * per layer: one fused-QKV GEMM (library GEMM, the D^-1/2 scaling folded into the Q rows), `mmgl_encattn_fwd`
-    (hand-written flash-style HIP kernel reading Q/K/V straight out of the fused buffer), output GEMM,
-    `mmgl_add_layernorm_fwd` (residual add + LayerNorm in one pass), FFN GEMMs with `mmgl_activation_fwd` in place;
+  * per layer: one fused-QKV GEMM (`mmgl_gemm_nt`: the persistent ping-pong MFMA kernel, the D^-1/2 scaling folded into
+    the Q rows), `mmgl_encattn_fwd` (hand-written flash-style HIP kernel reading Q/K/V straight out of the fused buffer),
+    output GEMM, `mmgl_add_layernorm_fwd` (residual add + LayerNorm in one pass), FFN GEMMs with GELU / quick-GELU in the
+    epilogue of the first one;
   * the last layer only produces what is consumed: keys/values for all tokens, but attention output, output projection,
     FFN and norms for the first (CLS) row of every sequence only.
 
-Forward only, no autograd (the encoders are frozen, reference :922-934).  Anything this path does not cover (CPU tensors,
-other architectures, relative position embeddings, a sequence whose first token is masked) returns None and the caller
-uses the HF module itself.
+Forward only, no autograd (the encoders are frozen, reference :922-934).  Architectures this path does not cover
+(`supports()` is False: relative position embeddings, exotic activations, CLIP's text tower) keep their HF forward; inputs
+it cannot take (CPU tensors, a sequence whose first token is masked) raise.
 """
 import math
 
 import torch
-import torch.nn.functional as F
 
 from .. import ops
 
@@ -39,7 +39,7 @@ class _Fused:
         self.layers = None
 
     def get(self, triples, scale):
-        key = _key(*[t[0].weight for t in triples], *[t[2].weight for t in triples])
+        key = _key(*[m.weight for t in triples for m in t], *[m.bias for t in triples for m in t])
         if key != self.key:
             layers = []
             for q, k, v in triples:
@@ -89,18 +89,29 @@ class PackedTextEncoder:
         return self._pos_type[1]
 
     @torch.no_grad()
-    def cls(self, ids, am):
+    def cls(self, ids, am, lens_host=None):
+        """lens_host = (int32 CPU tensor of the row lengths, bool: every row starts with a valid token), known on the host
+        from the collate (modelling_cross_attention.host_metadata): with it this pass never synchronises with the device."""
         m = self.model
         cfg = m.config
-        if not ids.is_cuda or ids.shape[0] == 0:
-            return None
+        if not ids.is_cuda:
+            raise RuntimeError("PackedTextEncoder: GPU tensors only (mmgl_amd has no CPU path)")
         n, L = ids.shape
+        if n == 0:
+            return ids.new_zeros(0, cfg.hidden_size, dtype=m.embeddings.word_embeddings.weight.dtype)
         amb = am != 0
         lens = amb.sum(1)
-        host = torch.stack([lens, amb[:, 0].to(lens.dtype)]).cpu()          # the one host sync of the text pass
-        if not bool(host[1].all()):
-            return None                      # a sequence without its first token: CLS row would not be row 0 of the pack
-        total, max_len = int(host[0].sum()), int(host[0].max())
+        if lens_host is None:
+            host = torch.stack([lens, amb[:, 0].to(lens.dtype)]).cpu()      # the one host sync of the text pass
+            lens_cpu, first_ok = host[0], bool(host[1].all())
+        else:
+            lens_cpu, first_ok = lens_host
+            if lens_cpu.numel() != n:
+                raise ValueError(f"PackedTextEncoder: host metadata describes {lens_cpu.numel()} sequences, the batch has {n}")
+        if not first_ok:
+            raise ValueError("PackedTextEncoder: every neighbor text must start with a valid token (the CLS row is row 0 of its "
+                             "packed sequence); tokenizers pad on the right (reference data.py:457)")
+        total, max_len = int(lens_cpu.sum()), int(lens_cpu.max())
         cu = _cu_from_lens(lens)
         flat = amb.reshape(-1)
         tok = torch.nonzero_static(flat, size=total).squeeze(1) if hasattr(torch, "nonzero_static") else flat.nonzero().squeeze(1)
@@ -119,21 +130,22 @@ class PackedTextEncoder:
         fused = self._fused.get([(l.attention.self.query, l.attention.self.key, l.attention.self.value) for l in layers],
                                 1.0 / math.sqrt(hid // H))
         first_rows = cu[:-1].long()
+        act = ops.ACT_CODES[cfg.hidden_act]
         es = h.element_size()                # algorithmic work of one attention call (for the bench's per-kernel report)
-        work_all = dict(flops=4.0 * float((host[0].double() ** 2).sum()) * hid, bytes=4.0 * total * hid * es)
+        work_all = dict(flops=4.0 * float((lens_cpu.double() ** 2).sum()) * hid, bytes=4.0 * total * hid * es)
         work_cls = dict(flops=4.0 * total * hid, bytes=2.0 * (total + n) * hid * es)
         for li, layer in enumerate(layers):
             last = li == len(layers) - 1
-            qkv = F.linear(h, *fused[li])
+            qkv = ops.gemm_nt(h, *fused[li])
             ctx = ops.encoder_attention(qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:], cu, H, max_len, q_rows=1 if last else None,
                                         work=work_cls if last else work_all)
             if last:                         # only the CLS rows are consumed downstream
                 ctx, h = ctx.index_select(0, first_rows), h.index_select(0, first_rows)
             ao = layer.attention.output
-            h1 = ops.add_layer_norm(F.linear(ctx, ao.dense.weight, ao.dense.bias), h, ao.LayerNorm.weight, ao.LayerNorm.bias, cfg.layer_norm_eps)
-            f = ops.activation_(F.linear(h1, layer.intermediate.dense.weight, layer.intermediate.dense.bias), cfg.hidden_act)
+            h1 = ops.add_layer_norm(ops.gemm_nt(ctx, ao.dense.weight, ao.dense.bias), h, ao.LayerNorm.weight, ao.LayerNorm.bias, cfg.layer_norm_eps)
+            f = ops.gemm_nt(h1, layer.intermediate.dense.weight, layer.intermediate.dense.bias, act=act)
             lo = layer.output
-            h = ops.add_layer_norm(F.linear(f, lo.dense.weight, lo.dense.bias), h1, lo.LayerNorm.weight, lo.LayerNorm.bias, cfg.layer_norm_eps)
+            h = ops.add_layer_norm(ops.gemm_nt(f, lo.dense.weight, lo.dense.bias), h1, lo.LayerNorm.weight, lo.LayerNorm.bias, cfg.layer_norm_eps)
         return h                             # [n, hidden]
 
 
@@ -163,8 +175,10 @@ class PackedVisionEncoder:
     def pooled(self, pixel_values):
         core = self._core(self.model)
         cfg = self.model.config
-        if not pixel_values.is_cuda or pixel_values.shape[0] == 0:
-            return None
+        if not pixel_values.is_cuda:
+            raise RuntimeError("PackedVisionEncoder: GPU tensors only (mmgl_amd has no CPU path)")
+        if pixel_values.shape[0] == 0:
+            return pixel_values.new_zeros(0, cfg.hidden_size)
         e = core.embeddings(pixel_values)                                   # patch GEMM + class token + positions: [n, S, hid]
         n, S, hid = e.shape
         H = cfg.num_attention_heads
@@ -174,21 +188,22 @@ class PackedVisionEncoder:
         layers = list(core.encoder.layers)
         fused = self._fused.get([(l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj) for l in layers], 1.0 / math.sqrt(hid // H))
         first_rows = cu[:-1].long()
+        act = ops.ACT_CODES[cfg.hidden_act]
         y = ops.layer_norm(x, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, eps) if layers else None
         es = x.element_size()
         work_all = dict(flops=4.0 * n * S * S * hid, bytes=4.0 * n * S * hid * es)
         work_cls = dict(flops=4.0 * n * S * hid, bytes=2.0 * (n * S + n) * hid * es)
         for li, layer in enumerate(layers):
             last = li == len(layers) - 1
-            qkv = F.linear(y, *fused[li])
+            qkv = ops.gemm_nt(y, *fused[li])
             ctx = ops.encoder_attention(qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:], cu, H, S, q_rows=1 if last else None,
                                         work=work_cls if last else work_all)
             if last:
                 ctx, x = ctx.index_select(0, first_rows), x.index_select(0, first_rows)
-            a = F.linear(ctx, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias)
+            a = ops.gemm_nt(ctx, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias)
             x, y2 = ops.add_layer_norm(a, x, layer.layer_norm2.weight, layer.layer_norm2.bias, eps, return_sum=True)
-            f = ops.activation_(F.linear(y2, layer.mlp.fc1.weight, layer.mlp.fc1.bias), cfg.hidden_act)
-            f2 = F.linear(f, layer.mlp.fc2.weight, layer.mlp.fc2.bias)
+            f = ops.gemm_nt(y2, layer.mlp.fc1.weight, layer.mlp.fc1.bias, act=act)
+            f2 = ops.gemm_nt(f, layer.mlp.fc2.weight, layer.mlp.fc2.bias)
             if last:
                 return ops.add_layer_norm(f2, x, core.post_layernorm.weight, core.post_layernorm.bias, eps)
             nxt = layers[li + 1].layer_norm1

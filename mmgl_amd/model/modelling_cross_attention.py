@@ -1,12 +1,15 @@
 """Decoder-only LM with interleaved tanh-gated neighbor cross-attention layers, MI355X-native.
 
 Mirrors the module API of the reference's model/modelling_cross_attention.py (class names, constructor
-arguments, forward signatures, state_dict key names, ValueErrors) so `run_generation` and checkpoints
-interchange, but every trainable op of the neighbor path runs through the hand-written HIP kernels of
-libmmgl_hip.so (mmgl_amd.ops): fused-epilogue MFMA projections, the single-pass masked cross-attention core,
-LayerNorm, the gated residual(+dropout), the interleave scatter and the token cross-entropy.  The frozen OPT
-self-attention layers and the frozen RoBERTa / CLIP encoders are stock torch / transformers modules in this
-round (SURVEY.md 8f "next" rows 1-2).
+arguments, forward signatures, state_dict key names, ValueErrors) so `run_generation` and model checkpoints
+interchange, and every op of the hot path runs through the hand-written HIP kernels of libmmgl_hip.so (mmgl_amd.ops):
+  * gated cross-attention layers (trainable): fused-epilogue MFMA projections, the single-pass masked cross-attention
+    core, LayerNorm, the gated residual(+dropout);
+  * frozen OPT layers: one fused-QKV GEMM, causal flash attention reading Q/K/V in place, residual add folded into the
+    following LayerNorm, FFN GEMMs with the ReLU in the epilogue and its backward in the epilogue of fc2's dgrad --
+    all GEMMs on the persistent ping-pong MFMA kernel (csrc/gemm8p.hip), dgrads against cached W^T copies;
+  * lm_head + shifted token cross-entropy, the interleave scatter, learned positions;
+  * frozen RoBERTa / CLIP encoders: packed (padding-free) forward in encoders.py on the same kernels.
 
 Deliberate deviations from the reference (all documented in DESIGN.md):
   * `args.neighbor_layer_wise` is optional: default num_hidden_layers // num_neighbor_layers (:92 reads an
@@ -15,8 +18,11 @@ Deliberate deviations from the reference (all documented in DESIGN.md, SURVEY.md
     README pairs them; "cross_attention" is accepted too (:433, :1072, :1080 vs data.py:167).
   * the interleave buffer is allocated in the compute dtype on the device (:1095 allocates fp32 on the host).
   * `train()` returns self (:1029-1036 returns None).
-  * cross-attention takes the [B,S] key mask; the [B,1,T,S] additive mask (:545-546) is never materialised.
-GPU only: there is no CPU fallback (ops raise if tensors are not on the device).
+  * masks are never materialised: cross-attention takes the [B,S] key mask (:545-546 builds [B,1,T,S]), self-attention
+    the [B,T] key mask with causality implied (:455-476 builds [B,1,T,T]).  What the additive masks can express and the
+    kernels cannot (per-head masks, attention weights as an output, attention dropout, a sample whose first key is
+    masked) raises ValueError instead of taking a slower path.
+GPU only: there is no CPU fallback and no alternative backend (ops raise if tensors are not on the device).
 """
 import math
 import os
@@ -109,6 +115,13 @@ class MPTLearnedPositionalEmbedding(nn.Embedding):
         return F.embedding(positions, self.weight)
 
 
+def _lin(module: nn.Linear, x, **kw):
+    """nn.Linear on the HIP GEMMs: frozen parameters -> ops.frozen_linear (dgrad only, cached W^T), else ops.linear."""
+    if module.weight.requires_grad or (module.bias is not None and module.bias.requires_grad):
+        return ops.linear(x, module.weight, module.bias)
+    return ops.frozen_linear(x, module.weight, module.bias, **kw)
+
+
 class MPTAttention(nn.Module):
     """Multi-head attention; cross_attention=True attends over the neighbor tokens (reference :148-275)."""
 
@@ -130,7 +143,6 @@ class MPTAttention(nn.Module):
         self.cross_attention = cross_attention
         self.peft_type = config.peft_type
         self.v_proj = nn.Linear(self.embed_dim, self.embed_dim, bias=bias)
-        self.fused_self_attention = True
 
     # -- fused HIP path: projections with bias/scale epilogue + single-pass masked core
     def _forward_cross(self, hidden_states, neighbor_embeds, neighbor_attention_mask, layer_head_mask, output_attentions):
@@ -172,47 +184,23 @@ class MPTAttention(nn.Module):
             self.__dict__["_qkv_cache"] = cache
         return cache[1]
 
-    # -- frozen OPT self-attention: stock torch ops with the reference's additive-mask semantics
+    # -- causal self-attention of the (frozen) OPT layers: HIP flash kernels, no [B,1,T,T] mask, no [B,H,T,T] scores
     def _forward_self(self, hidden_states, attention_mask, layer_head_mask, output_attentions):
-        bsz, tgt_len, _ = hidden_states.shape
-        H, D = self.num_heads, self.head_dim
-        if attention_mask is not None and attention_mask.dim() == 2:
-            # [B,T] key-valid mask, causal implied: the HIP flash kernels (mmgl_selfattn_fwd/bwd) -- no [B,1,T,T] mask, no
-            # [B,H,T,T] scores, no head transposes.  MPTDecoder only hands this form over when key 0 of every sample is valid.
-            if layer_head_mask is not None or output_attentions or (self.training and self.dropout > 0):
-                raise ValueError("layer_head_mask / output_attentions / attention dropout need the unfused self-attention path")
-            fused = self._frozen_qkv()
-            if fused is not None:            # frozen layer: one QKV GEMM forward, one dgrad GEMM backward, no gradient adds
-                o = ops.selfattn_core_fused(ops.frozen_linear(hidden_states, *fused), attention_mask, H)
-                return self.out_proj(o), None, None
-            q = self.q_proj(hidden_states) * self.scaling
-            o = ops.selfattn_core(q, self.k_proj(hidden_states), self.v_proj(hidden_states), attention_mask, H)
-            return self.out_proj(o), None, None
-        q = (self.q_proj(hidden_states) * self.scaling).view(bsz, tgt_len, H, D).transpose(1, 2)
-        k = self.k_proj(hidden_states).view(bsz, tgt_len, H, D).transpose(1, 2)
-        v = self.v_proj(hidden_states).view(bsz, tgt_len, H, D).transpose(1, 2)
-        if (self.fused_self_attention and attention_mask is not None and attention_mask.dtype == torch.bool
-                and layer_head_mask is None and not output_attentions and not (self.training and self.dropout > 0)):
-            # torch's fused SDPA with the boolean (causal & key-valid) mask: kept as an alternative backend
-            o = F.scaled_dot_product_attention(q, k, v, attn_mask=attention_mask, scale=1.0)
-            o = o.transpose(1, 2).reshape(bsz, tgt_len, self.embed_dim)
-            return self.out_proj(o), None, None
-        w = torch.matmul(q, k.transpose(-1, -2))
-        if attention_mask is not None:
-            if attention_mask.size() != (bsz, 1, tgt_len, tgt_len):
-                raise ValueError(f"Attention mask should be of size {(bsz, 1, tgt_len, tgt_len)}, but is {attention_mask.size()}")
-            w = torch.clamp_min(w + attention_mask, torch.finfo(w.dtype).min)
-        if w.dtype == torch.float16:
-            w = F.softmax(w, dim=-1, dtype=torch.float32).to(torch.float16)
+        H = self.num_heads
+        if attention_mask is None or attention_mask.dim() != 2:
+            raise ValueError("self-attention takes the [bsz, seq_len] key mask (causality is implied); additive 4-D masks are "
+                             f"not materialised on this path (got {None if attention_mask is None else tuple(attention_mask.shape)})")
+        if layer_head_mask is not None or output_attentions or (self.training and self.dropout > 0):
+            raise ValueError("layer_head_mask / output_attentions / attention dropout are not available on the fused self-attention kernels")
+        fused = self._frozen_qkv()
+        if fused is not None:                # frozen layer: one QKV GEMM forward, one dgrad GEMM backward, no gradient adds
+            o = ops.selfattn_core_fused(ops.frozen_linear(hidden_states, *fused), attention_mask, H)
         else:
-            w = F.softmax(w, dim=-1)
-        if layer_head_mask is not None:
-            if layer_head_mask.size() != (H,):
-                raise ValueError(f"Head mask for a single layer should be of size {(H,)}, but is {layer_head_mask.size()}")
-            w = layer_head_mask.view(1, -1, 1, 1) * w
-        p = F.dropout(w, p=self.dropout, training=self.training)
-        o = torch.matmul(p, v).transpose(1, 2).reshape(bsz, tgt_len, self.embed_dim)
-        return self.out_proj(o), (w if output_attentions else None), None
+            q = ops.linear(hidden_states, self.q_proj.weight, self.q_proj.bias, out_scale=self.scaling)
+            k = ops.linear(hidden_states, self.k_proj.weight, self.k_proj.bias)
+            v = ops.linear(hidden_states, self.v_proj.weight, self.v_proj.bias)
+            o = ops.selfattn_core(q, k, v, attention_mask, H)
+        return _lin(self.out_proj, o), None, None
 
     def forward(self, hidden_states, attention_mask=None, neighbor_embeds=None, neighbor_attention_mask=None,
                 past_key_value=None, layer_head_mask=None, output_attentions=False):
@@ -290,13 +278,13 @@ class MPTDecoderLayer(nn.Module):
         return h, attn_w
 
     def _forward_self(self, h, attention_mask, layer_head_mask, output_attentions, defer_residual=False):
-        """Frozen OPT layer: GEMMs are library calls (hipBLASLt); attention (ops.selfattn_core*), LayerNorm, dropout +
-        residual run on this repo's HIP kernels.  Every `residual + dropout(branch)` is folded into the LayerNorm that
+        """OPT layer (frozen in every peft mode of the reference, :731-737): GEMMs, attention (ops.selfattn_core*), LayerNorm and
+        dropout + residual all run on this repo's HIP kernels.  Every `residual + dropout(branch)` is folded into the LayerNorm that
         follows it (ops.add_layer_norm_pair: one forward and one backward kernel per pair); the layer's last add can be
         left to the next layer's first LayerNorm (`defer_residual`, see _Deferred)."""
         pre = self.do_layer_norm_before
         ln1, ln2 = self.self_attn_layer_norm, self.final_layer_norm
-        fuse = isinstance(h, _Deferred) or (h.is_cuda and _FUSE_ADD_LN)
+        fuse = isinstance(h, _Deferred) or _FUSE_ADD_LN
         pair = lambda x, r, ln: ops.add_layer_norm_pair(x, r, ln.weight, ln.bias, ln.eps, self.dropout, self.training)
         if isinstance(h, _Deferred):
             if pre:
@@ -319,11 +307,14 @@ class MPTDecoderLayer(nn.Module):
                 h = self._ln(ln1, h)
             x = self._ln(ln2, h) if pre else h
         residual = h
-        frozen = x.is_cuda and not any(p.requires_grad for p in (*self.fc1.parameters(), *self.fc2.parameters()))
-        if frozen and self.activation_name == "relu" and self.fc1.bias is not None:
-            x = ops.frozen_linear(ops.frozen_linear(x, self.fc1.weight, self.fc1.bias, relu=True), self.fc2.weight, self.fc2.bias)
+        if self.activation_name == "relu":
+            # fc1's ReLU backward rides in the epilogue of fc2's dgrad GEMM (mask_dx): no pass over [M, ffn], nothing kept twice
+            frozen = not any(p.requires_grad for p in (*self.fc1.parameters(), *self.fc2.parameters()))
+            lin = ops.frozen_linear if frozen else ops.linear
+            kw = dict(relu=True) if frozen else dict(act="relu")
+            x = lin(lin(x, self.fc1.weight, self.fc1.bias, bwd_premasked=True, **kw), self.fc2.weight, self.fc2.bias, mask_dx=True)
         else:
-            x = self.fc2(self.activation_fn(self.fc1(x)))
+            x = _lin(self.fc2, self.activation_fn(_lin(self.fc1, x)))
         if fuse and pre and defer_residual:
             return _Deferred(residual, x, self.dropout, self.training), attn_w
         if fuse and not pre:
@@ -402,7 +393,6 @@ class MPTDecoder(MPTPreTrainedModel):
             if self.cross_attention and (l + 1) % self.neighbor_layer_wise == 0:
                 self.neighbor_layers.append(MPTDecoderLayer(config, cross_attention=True))
         self.gradient_checkpointing = False
-        self.fused_self_attention = True
         self.post_init()
 
     def get_input_embeddings(self):
@@ -422,7 +412,7 @@ class MPTDecoder(MPTPreTrainedModel):
 
     def forward(self, input_ids=None, attention_mask=None, head_mask=None, past_key_values=None, inputs_embeds=None,
                 neighbor_embeds=None, neighbor_attention_mask=None, use_cache=None, output_attentions=None,
-                output_hidden_states=None, return_dict=None):
+                output_hidden_states=None, return_dict=None, first_key_valid=False):
         output_attentions = bool(output_attentions)
         output_hidden_states = bool(output_hidden_states)
         return_dict = True if return_dict is None else return_dict
@@ -445,16 +435,17 @@ class MPTDecoder(MPTPreTrainedModel):
         elif attention_mask.shape[1] != seq_length:
             raise ValueError(f"The provided attention mask has length {attention_mask.shape[1]}, but its length should be "
                              f"{seq_length} (sum of the lengths of current and past inputs)")
-        causal_attention_mask = self._prepare_decoder_attention_mask(attention_mask, input_shape, inputs_embeds, 0)
-        if (self.fused_self_attention and not output_attentions and head_mask is None and self.config.attention_dropout == 0
-                and seq_length > 1 and inputs_embeds.is_cuda and bool((attention_mask[:, 0] != 0).all())):
-            # every query row keeps key 0 (sequences are right-padded, data.py:321-333), so no row is fully masked and
-            # (causal & key-valid) is equivalent to the additive finfo.min masks: hand the [B,T] mask to the flash kernels
-            if self.fused_self_attention == "sdpa":
-                keep = torch.ones(seq_length, seq_length, dtype=torch.bool, device=inputs_embeds.device).tril_()
-                causal_attention_mask = keep[None, None] & (attention_mask[:, None, None, :] != 0)
-            else:
-                causal_attention_mask = (attention_mask != 0).to(torch.uint8).contiguous()
+        if output_attentions or head_mask is not None or (self.training and self.config.attention_dropout > 0):
+            raise ValueError("output_attentions / head_mask / attention_dropout need materialised attention weights, which the fused "
+                             "self-attention kernels never form")
+        # The [B,1,T,T] additive mask (:455-476) is never built: the flash kernels take the [B,T] key mask, causality implied.
+        # That equals the reference's finfo.min arithmetic as long as no query row is fully masked, i.e. key 0 of every sample
+        # is valid -- true for the right-padded sequences of wikiweb2m/data.py:321-333.  The collate can vouch for it on the
+        # host (`first_key_valid`); otherwise the check is a device-side assert: no host synchronisation either way.
+        if not first_key_valid:
+            torch._assert_async((attention_mask[:, 0] != 0).all(),
+                                "MPTDecoder: attention_mask[:, 0] must be 1 for every sample (right-padded sequences)")
+        causal_attention_mask = (attention_mask != 0).to(torch.uint8).contiguous()
         key_valid = None
         if neighbor_attention_mask is not None:
             key_valid = _key_valid_from(neighbor_attention_mask).to(torch.uint8).contiguous()
@@ -463,7 +454,7 @@ class MPTDecoder(MPTPreTrainedModel):
 
         pos_embeds = self.embed_positions(attention_mask, 0)
         if self.project_in is not None:
-            inputs_embeds = self.project_in(inputs_embeds)
+            inputs_embeds = _lin(self.project_in, inputs_embeds)
         hidden_states = inputs_embeds + pos_embeds
 
         all_hidden_states = () if output_hidden_states else None
@@ -472,7 +463,7 @@ class MPTDecoder(MPTPreTrainedModel):
             raise ValueError(f"The `head_mask` should be specified for {len(self.layers)} layers, but it is for"
                              f" {head_mask.size()[0]}.")
 
-        defer = inputs_embeds.is_cuda and not output_hidden_states and _FUSE_ADD_LN
+        defer = not output_hidden_states and _FUSE_ADD_LN
         for idx, decoder_layer in enumerate(self.layers):
             if output_hidden_states:
                 all_hidden_states += (hidden_states,)
@@ -499,13 +490,11 @@ class MPTDecoder(MPTPreTrainedModel):
             if isinstance(hidden_states, _Deferred):
                 _, hidden_states = ops.add_layer_norm_pair(hidden_states.branch, hidden_states.residual, fln.weight, fln.bias, fln.eps,
                                                            hidden_states.p_drop, hidden_states.training)
-            elif hidden_states.is_cuda:
-                hidden_states = ops.layer_norm(hidden_states, fln.weight, fln.bias, fln.eps)
             else:
-                hidden_states = fln(hidden_states)
+                hidden_states = ops.layer_norm(hidden_states, fln.weight, fln.bias, fln.eps)
         hidden_states = _materialize(hidden_states)
         if self.project_out is not None:
-            hidden_states = self.project_out(hidden_states)
+            hidden_states = _lin(self.project_out, hidden_states)
         if output_hidden_states:
             all_hidden_states += (hidden_states,)
         if not return_dict:
@@ -585,14 +574,14 @@ class MPTForCausalLM(MPTPreTrainedModel):
 
     def forward(self, input_ids=None, attention_mask=None, head_mask=None, past_key_values=None, inputs_embeds=None,
                 labels=None, neighbor_embeds=None, neighbor_attention_mask=None, use_cache=None, output_attentions=None,
-                output_hidden_states=None, return_dict=None):
+                output_hidden_states=None, return_dict=None, first_key_valid=False):
         return_dict = True if return_dict is None else return_dict
         outputs = self.model.decoder(input_ids=input_ids, attention_mask=attention_mask, head_mask=head_mask,
                                      past_key_values=past_key_values, inputs_embeds=inputs_embeds,
                                      neighbor_embeds=neighbor_embeds, neighbor_attention_mask=neighbor_attention_mask,
                                      use_cache=use_cache, output_attentions=output_attentions,
-                                     output_hidden_states=output_hidden_states, return_dict=True)
-        logits = self.lm_head(outputs.last_hidden_state).contiguous()
+                                     output_hidden_states=output_hidden_states, return_dict=True, first_key_valid=first_key_valid)
+        logits = _lin(self.lm_head, outputs.last_hidden_state)
         loss = None
         if labels is not None:
             # tokens < n predict n (:831-836).  Instead of copying the [B,T-1,V] slice, every row is scored against the
@@ -619,7 +608,11 @@ class _PatchEmbedLinear(nn.Conv2d):
             return super().forward(x)
         n, c, hh, ww = x.shape
         cols = x.view(n, c, hh // p, p, ww // p, p).permute(0, 2, 4, 1, 3, 5).reshape(n * (hh // p) * (ww // p), c * p * p)
-        y = F.linear(cols, self.weight.view(self.out_channels, -1), self.bias)
+        w = self.weight.view(self.out_channels, -1)
+        if cols.is_cuda and not torch.is_grad_enabled():
+            y = ops.gemm_nt(cols.contiguous(), w, self.bias)        # frozen encoder: forward only, on the HIP GEMM
+        else:
+            y = F.linear(cols, w, self.bias)
         return y.view(n, hh // p, ww // p, self.out_channels).permute(0, 3, 1, 2)
 
 
@@ -629,13 +622,41 @@ def _conv_patch_embed_as_gemm(module: nn.Module):
             m.__class__ = _PatchEmbedLinear
 
 
-def _valid_rows(pos_ids):
-    """Indices (device LongTensor) of neighbor slots with pos_id > 0, or None when every slot is valid OR some sample has
-    no valid slot at all (then padded slots DO matter: a fully-masked sample attends uniformly over all its keys)."""
-    valid = (pos_ids > 0).cpu()                       # [B, N], tiny; the one host sync of the neighbor pass
+def _valid_rows_host(pos_ids_cpu):
+    """Indices (CPU LongTensor) of neighbor slots with pos_id > 0, or None when every slot is valid OR some sample has no valid
+    slot at all (then padded slots DO matter: a fully-masked sample attends uniformly over all its keys)."""
+    valid = pos_ids_cpu > 0
     if bool(valid.all()) or not bool(valid.any(dim=1).all()):
         return None
-    return valid.reshape(-1).nonzero().squeeze(1).to(pos_ids.device)
+    return valid.reshape(-1).nonzero().squeeze(1)
+
+
+def _valid_rows(pos_ids):
+    """Device version of _valid_rows_host for callers without host metadata: one host sync (the [B, N] position ids)."""
+    rows = _valid_rows_host(pos_ids.cpu())
+    return None if rows is None else rows.to(pos_ids.device)
+
+
+def host_metadata(batch):
+    """What the forward pass needs to know on the HOST, computed from a batch that is still in host memory (the collate
+    output, before the H2D copy): which neighbor slots are real (reference data.py:444-454 pads with pos_id 0), how long every
+    real neighbor text is (the packing of the padding-free encoder), and that every sequence starts with a valid token.
+    Passing it as `host_meta=` removes every device->host synchronisation from the training step."""
+    meta = {"first_key_valid": bool((batch["attention_mask"][:, 0] != 0).all())}
+    npos = batch.get("neighbor_pos_ids")
+    if npos is not None and "neighbor_attention_mask" in batch:
+        rows = _valid_rows_host(npos.cpu())
+        am = batch["neighbor_attention_mask"].cpu()
+        am = am.reshape(-1, am.shape[-1]) != 0
+        if rows is not None:
+            am = am.index_select(0, rows)
+        meta["text_rows"] = rows
+        meta["text_lens"] = am.sum(1).to(torch.int32)
+        meta["text_first_valid"] = bool(am[:, 0].all()) if am.numel() else True
+    ipos = batch.get("neighbor_images_pos_ids")
+    if ipos is not None:
+        meta["image_rows"] = _valid_rows_host(ipos.cpu())
+    return meta
 
 
 def encode_text_bucketed(text_model, ids, am, n_buckets=4, use_pooler_output=False):
@@ -782,17 +803,27 @@ class CrossAttentionModel(nn.Module):
             embs = embs + pos_emb(pos_ids.reshape(-1))
         return embs.reshape(batch_size, -1, n_tokens, embs.shape[-1] // n_tokens)
 
-    def get_text_embs(self, input_ids, attention_mask, pos_ids=None):
+    def get_text_embs(self, input_ids, attention_mask, pos_ids=None, host_meta=None):
         """[B,N,L] ids -> [B,N,n_text_tokens,d]  (reference :978-1004)."""
         batch_size, neighbor_num, seq_len = input_ids.shape
         ids, am = input_ids.reshape(-1, seq_len), attention_mask.reshape(-1, seq_len)
-        rows = _valid_rows(pos_ids) if (self.skip_padded_neighbors and pos_ids is not None) else None
+        rows, lens_host = None, None
+        if self.skip_padded_neighbors and pos_ids is not None:
+            if host_meta is not None and "text_rows" in host_meta:
+                rows = host_meta["text_rows"]
+                rows = None if rows is None else rows.to(ids.device, non_blocking=True)
+                lens_host = (host_meta["text_lens"], host_meta["text_first_valid"])
+            else:
+                rows = _valid_rows(pos_ids)
+        elif host_meta is not None and host_meta.get("text_rows", 0) is None and "text_lens" in host_meta:
+            lens_host = (host_meta["text_lens"], host_meta["text_first_valid"])
         with torch.no_grad():
             if rows is not None:
                 ids, am = ids.index_select(0, rows), am.index_select(0, rows)
             is_clip = "clip" in self.args.text_model
-            enc = self._packed_text.cls(ids, am) if (self.packed_encoders and self._packed_text is not None and not is_clip) else None
-            if enc is None:
+            if self.packed_encoders and self._packed_text is not None and not is_clip:
+                enc = self._packed_text.cls(ids, am, lens_host)
+            else:               # architectures without a packed HIP forward (CLIP's text tower): the HF module, length-bucketed
                 enc = encode_text_bucketed(self.text_model, ids, am, 1 if is_clip else self.text_length_buckets, use_pooler_output=is_clip)
             if rows is not None:
                 full = enc.new_zeros(batch_size * neighbor_num, enc.shape[-1])
@@ -803,10 +834,16 @@ class CrossAttentionModel(nn.Module):
             pooled = torch.tanh(ops.linear(enc.contiguous(), self.text_pooler.dense.weight, self.text_pooler.dense.bias))
         return self._project(pooled, self.text_embeddings, self.text_position_embeddings, pos_ids, batch_size, self.n_text_tokens)
 
-    def get_visual_embs(self, pixel_values, pos_ids=None):
+    def get_visual_embs(self, pixel_values, pos_ids=None, host_meta=None):
         """[B,N,3,H,W] pixels -> [B,N,n_visual_tokens,d]  (reference :1006-1027)."""
         batch_size, neighbor_num, pixel, width, height = pixel_values.shape
-        rows = _valid_rows(pos_ids) if (self.skip_padded_neighbors and pos_ids is not None) else None
+        rows = None
+        if self.skip_padded_neighbors and pos_ids is not None:
+            if host_meta is not None and "image_rows" in host_meta:
+                rows = host_meta["image_rows"]
+                rows = None if rows is None else rows.to(pixel_values.device, non_blocking=True)
+            else:
+                rows = _valid_rows(pos_ids)
         with torch.no_grad():
             pv = pixel_values.reshape(-1, pixel, width, height)
             if rows is not None:
@@ -816,8 +853,9 @@ class CrossAttentionModel(nn.Module):
                 pooled = pixel_values.new_zeros(0, hidden, dtype=next(self.visual_model.parameters()).dtype)
             else:
                 pv = pv.to(next(self.visual_model.parameters()).dtype)
-                pooled = self._packed_visual.pooled(pv) if (self.packed_encoders and self._packed_visual is not None) else None
-                if pooled is None:
+                if self.packed_encoders and self._packed_visual is not None:
+                    pooled = self._packed_visual.pooled(pv)
+                else:
                     pooled = self.visual_model(pv).pooler_output
             if rows is not None:
                 pooled = pooled.new_zeros(batch_size * neighbor_num, hidden).index_copy_(0, rows, pooled)
@@ -835,20 +873,22 @@ class CrossAttentionModel(nn.Module):
 
     def forward(self, input_ids, attention_mask, labels, images=None, image_positions=None, neighbor_input_ids=None,
                 neighbor_attention_mask=None, neighbor_pos_ids=None, text_locations=None, neighbor_images=None,
-                neighbor_images_pos_ids=None, image_locations=None):
+                neighbor_images_pos_ids=None, image_locations=None, host_meta=None):
+        """`host_meta` (optional, not in the reference's signature): the dict of `host_metadata(batch)` computed by the collate /
+        trainer while the batch was still in host memory; with it the step has no device->host synchronisation."""
         if self.neighbor_mode == "raw" or self.context == "section_only":
             neighbor_embeds, key_valid = None, None          # sanity path: the plain OPT (:1068-1071)
         elif self.cross_path and self.context == "text_only":
-            text = self.get_text_embs(neighbor_input_ids, neighbor_attention_mask, neighbor_pos_ids)
+            text = self.get_text_embs(neighbor_input_ids, neighbor_attention_mask, neighbor_pos_ids, host_meta)
             neighbor_embeds, key_valid = ops.neighbor_interleave(
                 text, None, torch.arange(text.shape[1], device=text.device).expand(text.shape[0], -1).contiguous(), None,
                 neighbor_pos_ids, None)
         elif self.cross_path and self.context in ("section_all", "all"):
-            text = self.get_text_embs(neighbor_input_ids, neighbor_attention_mask, neighbor_pos_ids)
-            visual = self.get_visual_embs(neighbor_images, neighbor_images_pos_ids)
+            text = self.get_text_embs(neighbor_input_ids, neighbor_attention_mask, neighbor_pos_ids, host_meta)
+            visual = self.get_visual_embs(neighbor_images, neighbor_images_pos_ids, host_meta)
             neighbor_embeds, key_valid = ops.neighbor_interleave(text, visual, text_locations, image_locations,
                                                                  neighbor_pos_ids, neighbor_images_pos_ids)
         else:
             raise ValueError(f"Neighbor mode: {self.neighbor_mode} and context: {self.context} are not supported.")
         return self.lm(input_ids=input_ids, attention_mask=attention_mask, labels=labels, neighbor_embeds=neighbor_embeds,
-                       neighbor_attention_mask=key_valid)
+                       neighbor_attention_mask=key_valid, first_key_valid=bool(host_meta and host_meta.get("first_key_valid")))

@@ -551,18 +551,20 @@ def adamw_step_(param, master, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
                                 eps, weight_decay, step, grad_scale, dtype_code(param), stream_ptr())
 
 
-# ------------------------------------------------------------------------------------------ frozen linears (library GEMMs)
-# The frozen decoder layers only ever need y = x W^T + b and dx = dy W.  Both are plain library GEMMs (hipBLASLt); what
-# this section adds is layout and epilogue choice: the dgrad runs as an "NT" GEMM against a cached W^T copy (10 % faster
-# than the "NN" form at the OPT-1.3B FFN / fused-QKV shapes, tools/probes/dgrad_layout.py) and fc1's ReLU rides in the
-# GEMM epilogue (no clamp pass, no pre-activation kept).
+# ------------------------------------------------------------------------------------------ frozen linears
+# The frozen decoder layers, lm_head and the encoders only ever need y = act(x W^T + b) and dx = dy W.  Both run on
+# mmgl_gemm_nt (the persistent ping-pong MFMA kernel of csrc/gemm8p.hip for large bf16 shapes): forward with the bias /
+# activation epilogue, dgrad as an NT GEMM against a cached W^T copy (the weights never change), and fc1's ReLU backward
+# folded into the epilogue of fc2's dgrad (zmask) -- no clamp pass, no pre-activation kept, no library GEMM.
 _WT_CACHE = {}
+ACT_CODES = {"none": 0, "relu": 1, "gelu": 2, "quick_gelu": 3, "gelu_new": 4, "gelu_pytorch_tanh": 4, "gelu_fast": 4}
 
 
-def _transposed(weight):
-    """W^T as a contiguous tensor, cached per weight OBJECT (weakref-checked: an id or an address can be reused by a later
-    tensor) and rebuilt when its storage / version / dtype changes (load_state_dict, .bfloat16(), flattening)."""
-    key = id(weight)
+def _transposed(weight, pad_to=1):
+    """W^T as a contiguous tensor [in, out_padded] (out zero-padded up to a multiple of `pad_to`), cached per weight OBJECT
+    (weakref-checked: an id or an address can be reused by a later tensor) and rebuilt when its storage / version / dtype
+    changes (load_state_dict, .bfloat16(), flattening)."""
+    key = (id(weight), pad_to)
     tag = (weight.data_ptr(), weight._version, weight.dtype, tuple(weight.shape))
     hit = _WT_CACHE.get(key)
     if hit is None or hit[0]() is not weight or hit[1] != tag:
@@ -570,46 +572,111 @@ def _transposed(weight):
             for k in [k for k, h in _WT_CACHE.items() if h[0]() is None]:
                 del _WT_CACHE[k]
         with torch.no_grad():
-            hit = (weakref.ref(weight), tag, weight.detach().t().contiguous())
+            wt = weight.detach().t()
+            n = wt.shape[1]
+            npad = (n + pad_to - 1) // pad_to * pad_to
+            if npad != n:
+                full = wt.new_zeros(wt.shape[0], npad)
+                full[:, :n] = wt
+                wt = full
+            hit = (weakref.ref(weight), tag, wt.contiguous())
         _WT_CACHE[key] = hit
     return hit[2]
 
 
+def gemm_nt(x2, w, bias=None, residual=None, zmask=None, act=0, out_scale=1.0, K=None, out=None):
+    """Raw mmgl_gemm_nt call: act((x2[:, :K] @ w[:, :K]^T + bias) * out_scale) [zeroed where zmask <= 0] [+ residual].
+    x2 [M, >=K] and w [N, >=K] are row-major with unit column stride (their row strides are passed as ldx / ldw: K may exceed
+    x2's row length when the matching columns of w are zero padding).  No autograd."""
+    require_cuda(x2, w)
+    M, N = x2.shape[0], w.shape[0]
+    K = x2.shape[1] if K is None else K
+    if x2.stride(1) != 1 or w.stride(1) != 1:
+        raise ValueError("gemm_nt: operands need unit column stride")
+    y = torch.empty(M, N, dtype=x2.dtype, device=x2.device) if out is None else out
+    if M == 0:
+        return y
+    _lib.call("mmgl_gemm_nt", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x2.element_size()),
+              ptr(x2), x2.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(residual), ptr(zmask), ptr(y), y.stride(0), M, N, K, act,
+              float(out_scale), dtype_code(x2), stream_ptr())
+    return y
+
+
+def _gemm_nt_padded(x2, w, bias=None, zmask=None, act=0, K=None):
+    """gemm_nt for feature counts the MFMA kernels cannot address (K not a multiple of one 16-byte chunk, N not a multiple
+    of 8 -- tiny test vocabularies, the Laplacian-PE width): operands are zero-padded, the result sliced back."""
+    kq = 8 if x2.dtype == torch.bfloat16 else 4
+    Kx = x2.shape[1] if K is None else K
+    N = w.shape[0]
+    pk, pn = (-Kx) % kq, (-N) % 8
+    if not pk and not pn:
+        return gemm_nt(x2, w, bias, zmask=zmask, act=act, K=K)
+    x2 = F.pad(x2[:, :Kx], (0, pk)) if pk else x2
+    w = F.pad(w[:, :Kx], (0, pk, 0, pn))
+    bias = F.pad(bias, (0, pn)) if (bias is not None and pn) else bias
+    zmask = F.pad(zmask, (0, pn)) if (zmask is not None and pn) else zmask
+    y = gemm_nt(x2.contiguous(), w.contiguous(), bias, zmask=zmask, act=act, K=Kx + pk)
+    return y[:, :N].contiguous() if pn else y
+
+
 class _FrozenLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, cache_wt):
-        x2 = x.reshape(-1, x.shape[-1])
-        if relu:
-            y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False)
-            ctx.save_for_backward(y, weight)
-        else:
-            y = F.linear(x2, weight, bias)
-            ctx.save_for_backward(weight)
-        ctx.relu, ctx.cache_wt = relu, cache_wt
-        return y.view(*x.shape[:-1], weight.shape[0])
+    def forward(ctx, x, weight, bias, act, mask_dx, premasked):
+        require_cuda(x, weight)
+        K, N = weight.shape[1], weight.shape[0]
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+        b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
+        y = _gemm_nt_padded(x2, w.contiguous(), b, act=act)
+        # premasked: the consumer folds this layer's ReLU backward into its own dgrad (mask_dx there): differentiate as a plain
+        # linear and keep nothing.  mask_dx: x2 is a ReLU output whose backward rides in this layer's dgrad epilogue.
+        ctx.save_for_backward(weight, y if (act == 1 and not premasked) else None, x2 if mask_dx else None)
+        ctx.act = 0 if premasked else act
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        if ctx.relu:
-            y, weight = ctx.saved_tensors
-            g = torch.ops.aten.threshold_backward(dy.reshape(y.shape), y, 0)
-        else:
-            (weight,) = ctx.saved_tensors
-            g = dy.reshape(-1, dy.shape[-1])
-        dx = F.linear(g, _transposed(weight)) if ctx.cache_wt else g @ weight
-        return dx.view(*dy.shape[:-1], weight.shape[1]), None, None, None, None
+        weight, y, xmask = ctx.saved_tensors
+        N, K = weight.shape
+        g = dy.reshape(-1, N)
+        if not g.is_contiguous():
+            g = g.contiguous()
+        if ctx.act == 1:
+            gm = torch.empty_like(g)
+            _lib.call("mmgl_relu_bwd", dict(bytes=3.0 * g.numel() * g.element_size()), ptr(g), ptr(y), ptr(gm), g.numel(), dtype_code(g), stream_ptr())
+            g = gm
+        elif ctx.act:
+            raise RuntimeError("frozen_linear: only the ReLU epilogue is differentiable")
+        # dx[M,K] = g[M,N] @ W[N,K]  ==  NT GEMM against W^T [K, Npad]; the contraction length is padded to a multiple of 128
+        # with zero columns of W^T (lm_head: N = vocab = 50272), g is read with its own row stride
+        pad = 128 if (g.dtype == torch.bfloat16 and N % 128) else 1
+        wt = _transposed(weight, pad) if weight.dtype == g.dtype else weight.detach().to(g.dtype).t().contiguous()
+        kk = wt.shape[1]
+        if kk != N and not lib().mmgl_gemm_nt_fast(g.shape[0], K, kk, N, kk, K, dtype_code(g)):
+            wt, kk = wt[:, :N].contiguous(), N                # shape not on the fast path: dense operands
+        dx = _gemm_nt_padded(g, wt, zmask=xmask, K=kk)
+        return dx.view(ctx.xshape), None, None, None, None, None
 
 
-_DGRAD_WT = os.environ.get("MMGL_DGRAD_WT", "1") != "0"          # A/B switch: NT dgrad against the cached W^T
-
-
-def frozen_linear(x, weight, bias, relu=False, cache_wt=None):
-    """(relu)(x W^T + b) for a FROZEN nn.Linear (reference :194-199, :273, :352-355 inside the frozen LM layers)."""
+def frozen_linear(x, weight, bias, relu=False, mask_dx=False, bwd_premasked=False, act=None):
+    """act(x W^T + b) for a FROZEN nn.Linear (reference :194-199, :273, :352-355 inside the frozen LM layers, lm_head :826).
+    mask_dx / bwd_premasked: as in `linear` -- `h = frozen_linear(x, W1, b1, relu=True, bwd_premasked=True);
+    y = frozen_linear(h, W2, b2, mask_dx=True)` puts fc1's ReLU backward into the epilogue of fc2's dgrad GEMM."""
     if weight.requires_grad or (bias is not None and bias.requires_grad):
         raise ValueError("frozen_linear: weight and bias must be frozen (requires_grad=False)")
-    if relu and bias is None:
-        raise ValueError("frozen_linear: the ReLU epilogue needs a bias")
-    return _FrozenLinear.apply(x, weight, bias, bool(relu), _DGRAD_WT if cache_wt is None else bool(cache_wt))
+    if x.shape[-1] != weight.shape[1]:
+        raise ValueError(f"frozen_linear: x has {x.shape[-1]} features, weight expects {weight.shape[1]}")
+    code = 1 if relu else ACT_CODES.get(act or "none")
+    if code is None:
+        raise ValueError(f"frozen_linear: activation {act!r} is not fused")
+    if code > 1 and torch.is_grad_enabled() and x.requires_grad:
+        raise ValueError("frozen_linear: GELU epilogues are forward-only (frozen encoders); use relu / none under autograd")
+    if bwd_premasked and code != 1:
+        raise ValueError("frozen_linear: bwd_premasked needs the ReLU epilogue")
+    return _FrozenLinear.apply(x, weight, bias, code, bool(mask_dx), bool(bwd_premasked))
 
 
 def frozen_linear_relu(x, weight, bias):
@@ -617,9 +684,6 @@ def frozen_linear_relu(x, weight, bias):
 
 
 # ------------------------------------------------------------------------------------------ frozen encoders (forward only)
-ACT_CODES = {"relu": 1, "gelu": 2, "quick_gelu": 3, "gelu_new": 4, "gelu_pytorch_tanh": 4, "gelu_fast": 4}
-
-
 def encoder_attention(q, k, v, cu_seqlens, num_heads, max_len, q_rows=None, work=None):
     """Bidirectional attention over packed sequences (no padding rows exist).  q, k, v: [ntok, H*D] views with a common
     row stride (e.g. the three column slices of a fused-QKV output); q pre-scaled by D^-1/2; cu_seqlens int32 [nseq+1].

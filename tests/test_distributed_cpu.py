@@ -121,3 +121,60 @@ def test_engine_single_process_state_dict_roundtrip():
     # every trainable parameter is a view into the flat buffers
     for p, o in zip(eng.params, eng.offsets):
         assert p.data_ptr() == eng.flat_param[o:].data_ptr() and p.grad.data_ptr() == eng.flat_grad[o:].data_ptr()
+
+
+def test_optimizer_state_interchanges_with_torch_adamw_over_all_parameters(tmp_path):
+    """The reference builds torch.optim.AdamW(model.parameters()) over ALL parameters (run_generation.py:328) and stores its
+    state_dict in the checkpoint (:411).  The engine's optimizer state must round-trip with that index space BY NAME in both
+    directions, through torch.save / torch.load(weights_only=True)."""
+    from mmgl_amd.distributed import DataParallelEngine
+    torch.manual_seed(0)
+    x = [torch.randn(5, 6) for _ in range(4)]
+    # --- "reference side": AdamW over all parameters (frozen ones included), two steps
+    m_ref = Toy()
+    opt = torch.optim.AdamW(m_ref.parameters(), lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8)
+    for t in range(2):
+        opt.zero_grad()
+        m_ref(x[t]).backward()
+        opt.step()
+    ck = tmp_path / "ref.pt"
+    torch.save({"optimizer": opt.state_dict()}, ck)
+    # --- engine resumes from the reference's optimizer state
+    m = Toy()
+    m.load_state_dict(m_ref.state_dict())
+    eng = DataParallelEngine(m, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01, fused=False, master_weights=False)
+    eng.load_state_dict(torch.load(ck, weights_only=True)["optimizer"])
+    assert eng.step_count == 2
+    for t in range(2, 4):                               # two more steps on both sides must stay identical
+        opt.zero_grad(); m_ref(x[t]).backward(); opt.step()
+        m(x[t]).backward(); eng.finish_backward(); eng.step(); eng.zero_grad()
+    for (n, a), (_, b) in zip(m.named_parameters(), m_ref.named_parameters()):
+        assert torch.allclose(a, b, atol=1e-6), n
+    # --- and back: torch AdamW over all parameters accepts the engine's state_dict
+    ck2 = tmp_path / "eng.pt"
+    torch.save({"optimizer": eng.state_dict()}, ck2)
+    sd = torch.load(ck2, weights_only=True)["optimizer"]
+    opt2 = torch.optim.AdamW(m.parameters(), lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01, eps=1e-8)
+    opt2.load_state_dict(sd)
+    names = [n for n, _ in m.named_parameters()]
+    ref_state = opt.state_dict()["state"]
+    for i, st in opt2.state_dict()["state"].items():
+        assert torch.allclose(st["exp_avg"], ref_state[i]["exp_avg"], atol=1e-6), names[i]
+        assert int(st["step"]) == 4
+    # --- a checkpoint in a foreign index space (state but no matching entry) is an error, not a silent cold start
+    bad = {"state": {10_000: dict(step=torch.tensor(1.0), exp_avg=torch.zeros(1), exp_avg_sq=torch.zeros(1))},
+           "param_groups": sd["param_groups"], "param_names": None}
+    with pytest.raises(ValueError):
+        eng.load_state_dict(bad)
+
+
+def test_lr_schedule_follows_the_reference_step_order():
+    """optimizer.step() runs at the current lr, then scheduler.step() (run_generation.py:486-494): the warm-up's first optimizer
+    step uses lr 0 and step n uses base * (n - 1) / warmup."""
+    from mmgl_amd.language_modelling.run_generation import WarmupStepLR
+    s = WarmupStepLR(base_lr=1.0, warmup=4, step_size=3, gamma=0.5)
+    used = []
+    for _ in range(9):
+        used.append(s.get_last_lr()[0])     # what train_loop hands to engine.step()
+        s.step()
+    assert used == [0.0, 0.25, 0.5, 0.75, 1.0, 1.0, 1.0, 0.5, 0.5]

@@ -110,10 +110,15 @@ def test_packed_text_encoder_matches_hf(dtype, tol, hidden, heads, layers, inter
     got = PackedTextEncoder(model).cls(ids, am)
     assert got is not None and got.shape == ref.shape
     assert _rel(got, ref) < tol
-    # a sequence whose first token is masked is not packable: the caller must fall back to the HF module
+    # a sequence whose first token is masked is not packable: there is no fallback: it raises
     am2 = am.clone()
     am2[2, 0] = 0
-    assert PackedTextEncoder(model).cls(ids, am2) is None
+    with pytest.raises(ValueError):
+        PackedTextEncoder(model).cls(ids, am2)
+    # host metadata (lengths known from the collate) gives the same result without the device->host copy
+    lens_cpu = am.sum(1).to(torch.int32).cpu()
+    got2 = PackedTextEncoder(model).cls(ids, am, (lens_cpu, True))
+    assert torch.equal(got2, PackedTextEncoder(model).cls(ids, am))
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
