@@ -88,3 +88,55 @@ def test_g7_cider_golden():
     refs = ["the cat sat on the mat", "a dog barks at the mailman", "birds fly south in winter"]
     s, _ = Cider().compute_score({i: [r] for i, r in enumerate(refs)}, {i: [r] for i, r in enumerate(refs)})
     assert abs(s - 10.0) < 1e-9
+
+
+def test_on_disk_format_round_trip(tmp_path):
+    """the files the reference's preprocess_data.py writes -- three parquet files with bytes / per-section array
+    columns (:116-145), the id pickle keyed by split (:147-181), images named {page}_{section}_{idx}.{ext} (:201-202) -- read
+    back through load_wikiweb2m and WikiWeb2M.  Text-only items must equal the in-memory ones bit for bit; a page that has an
+    image file gets its pixels in the neighbor bundle at the slot its caption occupies (reference data.py:118-144, 363-381)."""
+    import pickle
+    from PIL import Image
+    from mmgl_amd.wikiweb2m import WikiWeb2M
+    from mmgl_amd.wikiweb2m.data import load_wikiweb2m
+    from mmgl_amd.wikiweb2m.synthetic import synthetic_id_list, synthetic_pages, synthetic_tokenizer
+    raw = tmp_path / "raw"
+    (raw / "images").mkdir(parents=True)
+    cols = ["page_id", "page_url", "page_title", "page_description", "section_title", "section_depth", "section_heading",
+            "section_parent_index", "section_summary", "section_rest_sentence", "image_url", "image_caption"]
+    splits = {"train": synthetic_pages(4, seed=3), "val": synthetic_pages(2, seed=4), "test": synthetic_pages(2, seed=5)}
+    for name, df in splits.items():
+        assert list(df.columns) == cols                                   # the schema of preprocess_data.py:120-121
+        df.to_parquet(raw / f"wikiweb2m_{name}_large.parquet")
+    with open(raw / "section_id_split_large.pkl", "wb") as f:
+        pickle.dump({k: synthetic_id_list(df) for k, df in splits.items()}, f)
+    train_df, val_df, test_df, id_list = load_wikiweb2m("section", root=str(raw))
+    assert set(id_list) == {"train", "val", "test"} and len(train_df) == 4 and len(val_df) == 2 and len(test_df) == 2
+    assert isinstance(train_df["page_title"].iloc[0], bytes) and isinstance(train_df["section_title"].iloc[0], np.ndarray)
+    tok = synthetic_tokenizer()
+    # (1) no image files yet: identical to the in-memory dataset (and therefore to the reference's golden items)
+    ds_mem = WikiWeb2M(data_args(), splits["train"], id_list["train"], tok, None, image_dir=str(raw / "images"))
+    ds_disk = WikiWeb2M(data_args(), train_df, id_list["train"], tok, None, image_dir=str(raw / "images"))
+    for i in range(len(ds_mem)):
+        a, b = ds_mem[i], ds_disk[i]
+        assert set(a) == set(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (i, k)
+    # (2) an image for (page 1000, section 1, second url): {page}_{section}_{idx}.{ext of the url}
+    page_id, section_id = id_list["train"][1]
+    assert section_id == 1
+    Image.fromarray((np.arange(20 * 30 * 3) % 255).astype(np.uint8).reshape(20, 30, 3)).save(raw / "images" / f"{page_id}_{section_id}_1.jpg")
+    seen = []
+
+    def extractor(img):                                                   # stands in for the CLIP feature extractor (no network)
+        seen.append(img.size)
+        return torch.full((3, 224, 224), 0.25)
+    ds_img = WikiWeb2M(data_args(), train_df, id_list["train"], tok, extractor, image_dir=str(raw / "images"))
+    with_img, without = ds_img[1], ds_disk[1]
+    assert seen and seen[0] == (30, 20)
+    assert int(with_img["neighbor_images_pos_ids"][0]) == 1 and int(without["neighbor_images_pos_ids"][0]) == 0
+    assert torch.equal(with_img["neighbor_images"][0], torch.full((3, 224, 224), 0.25)) and float(without["neighbor_images"].abs().max()) == 0
+    # the section image sits right after the page-info text and its caption follows it as a text neighbor (data.py:363-381)
+    assert int(with_img["image_locations"][0]) == 1 and int(with_img["text_locations"][1]) == 2
+    batch = next(iter(torch.utils.data.DataLoader(ds_img, batch_size=2)))
+    assert batch["neighbor_images"].shape == (2, 2, 3, 224, 224)

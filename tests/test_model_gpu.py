@@ -167,3 +167,41 @@ def test_bucketed_text_encoding_equals_padded():
         want = enc(input_ids=ids, attention_mask=am).last_hidden_state[:, 0]
         got = encode_text_bucketed(enc, ids, am, n_buckets=4)
     assert_close(got, want, 1e-5, "bucketed CLS")
+
+
+def test_initialize_lm_from_pretrained_round_trip(tmp_path):
+    """The HF loading path (reference model/modelling_cross_attention.py:951-976): a random OPT is written with
+    save_pretrained, `initialize_lm` reads it back through AutoConfig / AutoModelForCausalLM.from_pretrained and copies it
+    into the fork layer by layer.  With no neighbors the wrapper must then reproduce the HF model's logits and loss, and
+    the encoders must come from from_pretrained as well (:918-934)."""
+    from transformers import CLIPVisionModel, OPTForCausalLM, RobertaModel
+    from mmgl_amd.model import CrossAttentionModel
+    torch.manual_seed(3)
+    oc = tiny_opt_config(dropout=0.0)
+    hf = OPTForCausalLM(oc).eval()
+    lm_dir, txt_dir, vis_dir = tmp_path / "opt-tiny-ckpt", tmp_path / "roberta-tiny-ckpt", tmp_path / "clip-vit-tiny-ckpt"
+    hf.save_pretrained(lm_dir)
+    RobertaModel(tiny_roberta_config(), add_pooling_layer=False).save_pretrained(txt_dir)
+    CLIPVisionModel(tiny_clip_vision_config()).save_pretrained(vis_dir)
+    args = mpt_args(context="all", model_name_or_path=str(lm_dir), text_model=str(txt_dir), visual_model=str(vis_dir))
+    w = CrossAttentionModel(args, tokenizer=None)                       # no *_config: every sub-model goes through from_pretrained
+    # the copy is complete: every OPT tensor arrived under the fork's key names
+    hf_sd = hf.state_dict()
+    for k, v in w.lm.state_dict().items():
+        if "neighbor_layers" in k:
+            continue
+        assert torch.equal(v, hf_sd[k]), k
+    # trainable set = the cross-attention layers + projections (reference :731-737)
+    assert all(("neighbor_layers" in n) == p.requires_grad for n, p in w.lm.named_parameters())
+    w = w.cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, 128, (3, 24), generator=g)
+    am = torch.ones_like(ids)
+    am[1, 17:] = 0
+    ids = torch.where(am.bool(), ids, torch.ones_like(ids))
+    with torch.no_grad():
+        ref = hf(input_ids=ids, attention_mask=am, labels=ids)
+        w.neighbor_mode = "raw"                                        # the plain-OPT sanity path (:1068-1071)
+        out = w(input_ids=ids.cuda(), attention_mask=am.cuda(), labels=ids.cuda())
+    assert_close(out.logits, ref.logits, TOL, "logits vs HF OPT loaded from the same checkpoint")
+    assert_close(out.loss, ref.loss, TOL, "loss")
