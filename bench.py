@@ -120,15 +120,15 @@ def synthetic_batch(B, cfg, seed, device, Lin=512, Lout=128, Ln=512, vocab=50272
     return batch, valid_keys
 
 
-def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1):
-    """Time the CPU oracle on the same step (frozen encoders fwd, LM fwd+bwd w.r.t. the trainable set) for a bounded
-    sample.  fp32, all host cores.  Returns the JSON object for the bench line."""
+def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1, repeats=3):
+    """Time the CPU oracle on the same step (frozen encoders fwd, LM fwd+bwd w.r.t. the trainable set) on a bounded sample:
+    one warm-up, then the median of `repeats` runs of `n_samples` sample(s) each.  fp32, host cores.  Returns the JSON object
+    for the bench line."""
     from oracle import lm_ref, wrapper_ref
     # threads: torch/MKL fp32 GEMM peaks at ~32 threads on the GPU box's 2 x 64-core EPYC 9575F and collapses beyond
     # (tools/probes/cpu_threads.py: 1.44 TFLOP/s @32, 0.64 @64, 0.07 @256) -> use min(32, cpu_count)
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    t_build = time.time()
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     trainable = [k for k, p in model.named_parameters() if p.requires_grad]
     for k in trainable:
@@ -139,19 +139,28 @@ def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1):
     ocfg = lm_ref.LMConfig(vocab_size=lm_cfg.vocab_size, hidden_size=lm_cfg.hidden_size, num_attention_heads=lm_cfg.num_attention_heads,
                            ffn_dim=lm_cfg.ffn_dim, num_hidden_layers=lm_cfg.num_hidden_layers,
                            word_embed_proj_dim=lm_cfg.word_embed_proj_dim, neighbor_layer_wise=cfg["wise"])
-    t0 = time.time()
-    with torch.no_grad():
-        L = b["neighbor_input_ids"].shape[-1]
-        tl = text_model(input_ids=b["neighbor_input_ids"].reshape(-1, L), attention_mask=b["neighbor_attention_mask"].reshape(-1, L)).last_hidden_state
-        vp = visual_model(b["neighbor_images"].reshape(-1, 3, 224, 224)).pooler_output
-    logits, loss = wrapper_ref.cross_attention_model_forward(sd, ocfg, b, tl, vp, "all", 4)
-    loss.backward()
-    dt = time.time() - t0
+
+    def once():
+        for k in trainable:
+            sd[k].grad = None
+        t0 = time.time()
+        with torch.no_grad():
+            L = b["neighbor_input_ids"].shape[-1]
+            tl = text_model(input_ids=b["neighbor_input_ids"].reshape(-1, L), attention_mask=b["neighbor_attention_mask"].reshape(-1, L)).last_hidden_state
+            vp = visual_model(b["neighbor_images"].reshape(-1, 3, 224, 224)).pooler_output
+        logits, loss = wrapper_ref.cross_attention_model_forward(sd, ocfg, b, tl, vp, "all", 4)
+        loss.backward()
+        return time.time() - t0, float(loss.detach())
+
+    once()                                              # warm-up (thread pool, allocator)
+    runs = sorted(once() for _ in range(repeats))
+    dt, loss = runs[len(runs) // 2]
     model.text_model.to(batch["input_ids"].device)
     model.visual_model.to(batch["input_ids"].device)
     return dict(value=n_samples / dt, unit="samples/s", cores=cores, kind="port", seconds=round(dt, 2),
-                sample=f"{n_samples} sample(s) of the same synthetic batch: frozen encoders fwd + LM fwd + bwd (no optimizer step), "
-                       f"fp32 torch oracle (oracle/), {cores} threads", loss=float(loss))
+                runs_s=[round(r[0], 2) for r in runs],
+                sample=f"median of {repeats} runs (after 1 warm-up) of {n_samples} sample(s) of the same synthetic batch: frozen encoders fwd + LM "
+                       f"fwd + bwd (no optimizer step), fp32 torch oracle (oracle/), {cores} threads", loss=loss)
 
 
 def pmc_traffic(B, lm_cfg, cfg, dtype):
@@ -181,7 +190,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=2)
+    ap.add_argument("--cpu-samples", type=int, default=1)
+    ap.add_argument("--ref-batch", type=int, default=4, help="also report the step at the reference's default per-device batch (Arguments default 4, run_generation.py:124-126); 0 = skip")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -242,12 +252,15 @@ def main():
     d = lm_cfg.hidden_size
     esize = 2 if dtype == torch.bfloat16 else 4
 
+    n_steps_run = [0]
+
     def step():
         out = model(**batch)
         out.loss.backward()
         engine.finish_backward()
         engine.step()
         engine.zero_grad()
+        n_steps_run[0] += 1
         return out.loss
 
     for _ in range(args.warmup):
@@ -283,13 +296,35 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # ---- the same step at the reference's own default batch (launch-bound regime: GEMM M = 4 * 640), outside the timed region
+    ref_line = None
+    if args.ref_batch and args.ref_batch != args.batch:
+        keep = batch
+        batch, _ = synthetic_batch(args.ref_batch, cfg, seed=4321 + rank, device=device)
+        for _ in range(3):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_ref = 10
+        for _ in range(n_ref):
+            step()
+        torch.cuda.synchronize()
+        t1 = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+        t1 = float(t1.item())
+        ref_line = {"per_gpu_batch": args.ref_batch, "value": round(world * args.ref_batch * n_ref / t1, 3), "unit": "samples/s",
+                    "ms_per_step": round(1e3 * t1 / n_ref, 3), "steps": n_ref}
+        batch = keep
+
     # ---- gradient-exchange report (outside the timed region; every rank runs the same collectives)
     exchange = None
     if world > 1:
         ones = torch.ones(1, device=device)
         dist.all_reduce(ones)                                         # = number of ranks RCCL actually connected
-        ex_steps = max(1, args.warmup + args.steps + table_steps)
-        bytes_per_step = engine.exchange_bytes / ex_steps
+        bytes_per_step = engine.exchange_bytes / max(1, n_steps_run[0])
 
         def timed(fn, n):
             dist.barrier()
@@ -379,6 +414,8 @@ def main():
                                                   "peak_tflops": peak_tf, "scope": "GEMMs + attention core of the 4 gated cross-attention layers"}
             line["kernels_note"] = f"per C-ABI entry point over {table_steps} extra steps after the timed region"
             line["hip_path_ms_per_step"] = round(sum(s["ms_total"] for s in ks.values()) / table_steps, 2)
+        if ref_line is not None:
+            line["at_reference_batch"] = ref_line
         if exchange is not None:
             line["exchange"] = exchange
         if world == 1 and not args.no_cpu_baseline:

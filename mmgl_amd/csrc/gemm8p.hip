@@ -71,7 +71,12 @@ template <int ACT> __device__ __forceinline__ float p8_act(float v, float lo) {
 
 // lane id from the exec mask (v_mbcnt): recomputed where it is needed instead of keeping a register (or, under this kernel's
 // register pressure, a scratch slot and its vmcnt(0) reload) alive across the main loop
-__device__ __forceinline__ int p8_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// (asm volatile: the builtin form is loop-invariant to hipcc, which hoists it -- and everything derived from it -- to kernel entry)
+__device__ __forceinline__ int p8_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 
 #define P8_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define P8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -193,16 +198,34 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     };
     const float relu_lo = a.act == 1 ? 0.f : -3.0e38f;
     // epilogue of one quadrant (rows J0..J0+3 x fragment rows T0, T0+1 = 8 consecutive columns per lane): 4 x 16-byte stores
-    auto epi = [&](int J0, int T0) __attribute__((always_inline)) {
+    // per-lane byte offset of (row J, fragment-row half T0) inside the [M, ldy] output / zmask / residual
+    auto y_off = [&](int J, int T0) __attribute__((always_inline)) -> unsigned {
         const int ln = p8_lane();
         const int ncol_l = wc * 64 + 16 * (ln >> 4);         // column of this lane inside the tile
-        const bool ncol = n0 + ncol_l < a.N;
-        const unsigned vo = ncol ? (unsigned)(((wr * 128 + (ln & 15)) * a.ldy + n0 + ncol_l + 4 * T0) * 2) : 0xffffffffu;
+        return n0 + ncol_l < a.N ? (unsigned)((((wr * 128 + (ln & 15)) + J * 16) * a.ldy + n0 + ncol_l + 4 * T0) * 2) : 0xffffffffu;
+    };
+    // ZR kernels: the 16 zmask (else residual) vectors of the whole tile are requested up front, into the registers the
+    // K loop's fragments just vacated: one exposed memory latency per tile instead of one per quadrant
+    bf16x8 pre[16];
+    auto prefetch_zr = [&]() __attribute__((always_inline)) {
+        if constexpr (ZR) {
+            const bf16* src = a.zmask ? a.zmask : a.resid;
+            __amdgpu_buffer_rsrc_t dZ = y_desc(src, m0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int J0 = (q == 0 || q == 1) ? 0 : 4, T0 = (q == 0 || q == 3) ? 0 : 2;       // order of the epi() calls below
+                    pre[q * 4 + j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dZ, y_off(J0 + j, T0), 0, 0));
+                }
+        }
+    };
+    auto epi = [&](int q, int J0, int T0) __attribute__((always_inline)) {
         __amdgpu_buffer_rsrc_t dY = y_desc(a.Y, m0);
         const bf16x8 br = T0 ? braw1 : braw0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const unsigned off = ncol ? vo + (unsigned)((J0 + j) * 16 * a.ldy * 2) : 0xffffffffu;
+            const unsigned off = y_off(J0 + j, T0);
             const f32x4 lo = acc[T0][J0 + j], hi = acc[T0 + 1][J0 + j];
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
@@ -210,17 +233,19 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = p8_act<ACT>(v[e], relu_lo);
             if constexpr (ZR) {
+                const bf16x8 z = pre[q * 4 + j];
                 if (a.zmask) {
-                    __amdgpu_buffer_rsrc_t dZ = y_desc(a.zmask, m0);
-                    const bf16x8 z = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dZ, off, 0, 0));
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = ((float)z[e] > 0.f) ? v[e] : 0.f;
-                }
-                if (a.resid) {
-                    __amdgpu_buffer_rsrc_t dR = y_desc(a.resid, m0);
-                    const bf16x8 rr = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dR, off, 0, 0));
+                    if (a.resid) {
+                        __amdgpu_buffer_rsrc_t dR = y_desc(a.resid, m0);
+                        const bf16x8 rr = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dR, off, 0, 0));
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)z[e];
                 }
             }
             f32x8 o8 = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
@@ -287,10 +312,11 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
             P8_PHASE(rdW(fwA, 7), 1, 5, 3, P8_MM(fx, fwB, 4, 0));
         }
         // epilogue of tile (m0, n0), beside the partner wave's MFMAs (waves 0-3 and 4-7 reach it half a phase apart)
-        epi(0, 0);
-        epi(0, 2);
-        epi(4, 2);
-        epi(4, 0);
+        prefetch_zr();
+        epi(0, 0, 0);
+        epi(1, 0, 2);
+        epi(2, 4, 2);
+        epi(3, 4, 0);
         if (!have_next) break;
         ++it;
         m0 = m1;
