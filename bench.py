@@ -33,20 +33,35 @@ MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
 MFMA_F32_PEAK_TF = 157.3
 
 CONFIGS = {
-    # name: (lm dims, neighbors)
-    "opt-1.3b": dict(lm=dict(vocab_size=50272, hidden_size=2048, num_attention_heads=32, ffn_dim=8192, num_hidden_layers=24,
-                             max_position_embeddings=2048, word_embed_proj_dim=2048), nt=11, ni=5, wise=6,
-                     model_name="facebook/mpt-1.3b"),
-    "opt-125m": dict(lm=dict(vocab_size=50272, hidden_size=768, num_attention_heads=12, ffn_dim=3072, num_hidden_layers=12,
-                             max_position_embeddings=2048, word_embed_proj_dim=768), nt=2, ni=2, wise=3,
-                     model_name="facebook/mpt-125m"),
+    # name: LM dims, neighbors, model kind.  BASELINE.json configs[2] (default, the one `metric` is quoted on), [1], [3], [4].
+    "opt-1.3b": dict(kind="flamingo", lm=dict(vocab_size=50272, hidden_size=2048, num_attention_heads=32, ffn_dim=8192, num_hidden_layers=24,
+                                              max_position_embeddings=2048, word_embed_proj_dim=2048), nt=11, ni=5, wise=6,
+                     model_name="facebook/mpt-1.3b", batch=64, lin=512, lout=128, vocab=50272,
+                     metric="train samples/sec (OPT-1.3B flamingo, 16 neighbors)"),
+    "opt-125m": dict(kind="flamingo", lm=dict(vocab_size=50272, hidden_size=768, num_attention_heads=12, ffn_dim=3072, num_hidden_layers=12,
+                                              max_position_embeddings=2048, word_embed_proj_dim=768), nt=2, ni=2, wise=3,
+                     model_name="facebook/mpt-125m", batch=64, lin=512, lout=128, vocab=50272,
+                     metric="train samples/sec (OPT-125m flamingo, 4 neighbors)"),
+    # configs[3]: LoRA r=16 on q_proj / v_proj of OPT-1.3B, neighbors concatenated into the sequence (T = 640 + 64), lm_head trainable
+    "opt-1.3b-lora": dict(kind="lora", lm=dict(vocab_size=50272, hidden_size=2048, num_attention_heads=32, ffn_dim=8192, num_hidden_layers=24,
+                                               max_position_embeddings=2048, word_embed_proj_dim=2048), nt=11, ni=5, wise=6,
+                          model_name="facebook/opt-1.3b", batch=32, lin=512, lout=128, vocab=50272, lora_r=16,
+                          metric="train samples/sec (OPT-1.3B LoRA r=16, 16 neighbors, self-attention fusion)"),
+    # configs[4]: Llama-2-7B dims, 32 neighbors (22 text + 10 image) x 4 tokens, max_input_length 2048 -> T = 2176, S = 128
+    "llama-2-7b": dict(kind="llama", lm=dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                                             num_attention_heads=32, num_key_value_heads=32, max_position_embeddings=4096), nt=22, ni=10,
+                       wise=8, model_name="meta-llama/Llama-2-7b-hf", batch=8, lin=2048, lout=128, vocab=32000,
+                       metric="train samples/sec (Llama-2-7B flamingo, 32 neighbors, T=2176)"),
 }
 
 
 def hf_configs(cfg):
-    from transformers import CLIPVisionConfig, OPTConfig, RobertaConfig
-    lm = OPTConfig(do_layer_norm_before=True, dropout=0.1, attention_dropout=0.0, pad_token_id=1, bos_token_id=2,
-                   eos_token_id=2, **cfg["lm"])
+    from transformers import CLIPVisionConfig, LlamaConfig, OPTConfig, RobertaConfig
+    if cfg["kind"] == "llama":
+        lm = LlamaConfig(pad_token_id=0, bos_token_id=1, eos_token_id=2, attention_dropout=0.0, **cfg["lm"])
+    else:
+        lm = OPTConfig(do_layer_norm_before=True, dropout=0.1, attention_dropout=0.0, pad_token_id=1, bos_token_id=2,
+                       eos_token_id=2, **cfg["lm"])
     txt = RobertaConfig(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
                         max_position_embeddings=514, pad_token_id=1, type_vocab_size=1)
     vis = CLIPVisionConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
@@ -56,19 +71,24 @@ def hf_configs(cfg):
 
 def make_args(cfg, **kw):
     from mmgl_amd.language_modelling.run_generation import Arguments
-    a = Arguments(model_name_or_path=cfg["model_name"], context="all", neighbor_mode="embedding", peft_type="flamingo",
-                  max_text_neighbors=cfg["nt"], max_image_neighbors=cfg["ni"], decoder_only=True)
+    peft = {"flamingo": "flamingo", "llama": "flamingo", "lora": "lora"}[cfg["kind"]]
+    a = Arguments(model_name_or_path=cfg["model_name"], context="all", neighbor_mode="embedding", peft_type=peft,
+                  max_text_neighbors=cfg["nt"], max_image_neighbors=cfg["ni"], decoder_only=True, max_input_length=cfg["lin"],
+                  max_output_length=cfg["lout"])
     a.neighbor_layer_wise = cfg["wise"]
+    if cfg["kind"] == "lora":
+        a.lora_r, a.lora_alpha, a.lora_dropout, a.position_type = cfg["lora_r"], 32.0, 0.0, "none"
     for k, v in kw.items():
         setattr(a, k, v)
     return a
 
 
-def synthetic_batch(B, cfg, seed, device, Lin=512, Lout=128, Ln=512, vocab=50272):
+def synthetic_batch(B, cfg, seed, device, Ln=512):
     """WikiWeb2M-shaped batch of SURVEY.md 8(d): ragged prompt / summary / neighbor lengths, ragged neighbor counts,
     random interleave of the valid slots, padding slots last."""
     g = torch.Generator().manual_seed(seed)
     Nt, Ni = cfg["nt"], cfg["ni"]
+    Lin, Lout, vocab = cfg["lin"], cfg["lout"], cfg["vocab"]
     T = Lin + Lout
     ids = torch.randint(3, vocab, (B, T), generator=g)
     am = torch.ones(B, T, dtype=torch.long)
@@ -186,7 +206,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="opt-1.3b", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (reference default 4).  Sized for the 288 GB HBM and the 256-CU GEMM grid: 16 -> 197, 32 -> 208, 48 -> 233, 56 -> 229, 64 -> 243, 72 -> 233, 80 -> 238 samples/s on one MI355X (the dips are library-GEMM heuristics)")
+    ap.add_argument("--batch", type=int, default=0, help="0 = the config's default (64 for opt-1.3b).  " + "per-GPU batch (reference default 4).  Sized for the 288 GB HBM and the 256-CU GEMM grid: 16 -> 197, 32 -> 208, 48 -> 233, 56 -> 229, 64 -> 243, 72 -> 233, 80 -> 238 samples/s on one MI355X (the dips are library-GEMM heuristics)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -228,20 +248,31 @@ def main():
 
     from mmgl_amd import _lib
     from mmgl_amd.distributed import DataParallelEngine
-    from mmgl_amd.model import CrossAttentionModel
+    from mmgl_amd.model import CrossAttentionModel, SelfAttentionModel
     _lib.lib()                                        # fail loudly if the HIP extension is missing
 
     cfg = CONFIGS[args.config]
+    if not args.batch:
+        args.batch = cfg["batch"]
     lm_cfg, txt_cfg, vis_cfg = hf_configs(cfg)
     margs = make_args(cfg)
     torch.manual_seed(1234)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    with torch.device("cpu"):
-        model = CrossAttentionModel(margs, tokenizer=None, lm_config=lm_cfg, text_config=txt_cfg, visual_config=vis_cfg)
+    cls = SelfAttentionModel if cfg["kind"] == "lora" else CrossAttentionModel
+    if cfg["kind"] == "llama":                        # 7 B parameters: random-initialised directly on the GPU in the compute dtype
+        torch.set_default_dtype(dtype)
+        with torch.device(device):
+            model = cls(margs, tokenizer=None, lm_config=lm_cfg, text_config=txt_cfg, visual_config=vis_cfg)
+        torch.set_default_dtype(torch.float32)
+    else:
+        with torch.device("cpu"):
+            model = cls(margs, tokenizer=None, lm_config=lm_cfg, text_config=txt_cfg, visual_config=vis_cfg)
     with torch.no_grad():
         for n_, p in model.named_parameters():
             if n_.endswith("gating1") or n_.endswith("gating2"):
                 p.fill_(0.5)                          # numerically live cross-attention (init value 0 = identity)
+            if n_.endswith("lora_B"):
+                p.normal_(std=0.02)                   # numerically live adapters (init value 0 = identity)
     model = model.to(dtype).to(device)
     model.train()
     engine = DataParallelEngine(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.01)
@@ -251,6 +282,7 @@ def main():
     T = batch["input_ids"].shape[1]
     d = lm_cfg.hidden_size
     esize = 2 if dtype == torch.bfloat16 else 4
+    roof_name = "mmgl_lora_linear_fwd" if cfg["kind"] == "lora" else "mmgl_xattn_fwd"
 
     n_steps_run = [0]
 
@@ -268,7 +300,7 @@ def main():
     timing = not args.no_kernel_timing
     _lib.KernelTimer.reset()
     _lib.KernelTimer.enabled = timing
-    _lib.KernelTimer.only = {"mmgl_xattn_fwd"}        # timed region: HIP events around the roofline kernel only (24 launches/step)
+    _lib.KernelTimer.only = {roof_name}               # timed region: HIP events around the roofline kernel only
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -280,7 +312,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     _lib.KernelTimer.enabled = False
-    roof = _lib.KernelTimer.summary().get("mmgl_xattn_fwd") if timing else None
+    roof = _lib.KernelTimer.summary().get(roof_name) if timing else None
     table_steps = 0
     if timing:                                        # per-entry-point table: two more steps with events around EVERY call (the
         _lib.KernelTimer.reset()                      # ~1700 event pairs per step cost 1-2 % of throughput, so not in `value`)
@@ -298,7 +330,7 @@ def main():
 
     # ---- the same step at the reference's own default batch (launch-bound regime: GEMM M = 4 * 640), outside the timed region
     ref_line = None
-    if args.ref_batch and args.ref_batch != args.batch:
+    if args.ref_batch and args.ref_batch < args.batch:
         keep = batch
         batch, _ = synthetic_batch(args.ref_batch, cfg, seed=4321 + rank, device=device)
         for _ in range(3):
@@ -359,21 +391,29 @@ def main():
     if rank == 0:
         value = world * args.batch * args.steps / dt
         line = {
-            "metric": "train samples/sec (OPT-1.3B flamingo, 16 neighbors)" if args.config == "opt-1.3b"
-                      else f"train samples/sec ({args.config} flamingo)",
+            "metric": cfg["metric"],
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic WikiWeb2M-shaped batch (seeded), random-init weights",
             "samples_per_sec_per_gpu": round(value / world, 3),
-            "config": {"workload": f"{args.config} context=all neighbor_mode=embedding peft=flamingo, {cfg['nt']}+{cfg['ni']} neighbors x 4 tokens, "
-                                   f"T=640, roberta-base + clip-vit-base-patch16 frozen encoders, full train step (fwd+bwd+exchange+AdamW)",
+            "config": {"workload": f"{args.config} context=all neighbor_mode=embedding peft={margs.peft_type}"
+                                   + (f" r={cfg['lora_r']} (q_proj, v_proj; lm_head trainable), neighbors concatenated into the sequence" if cfg["kind"] == "lora" else "")
+                                   + f", {cfg['nt']}+{cfg['ni']} neighbors x 4 tokens, T={cfg['lin']}+{cfg['lout']}, roberta-base + clip-vit-base-patch16 frozen "
+                                     f"encoders, full train step (fwd+bwd+exchange+AdamW)",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "seq_len": T, "neighbor_keys": (cfg["nt"] + cfg["ni"]) * 4,
                        "trainable_params": n_train, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 4)},
         }
         if timing:
             ks = _lib.KernelTimer.summary()
             x = roof
-            if x:
+            if x and cfg["kind"] == "lora":
+                tf = x["flops"] / (x["ms_total"] * 1e-3) / 1e12
+                pk = MFMA_BF16_PEAK_TF if dtype == torch.bfloat16 else MFMA_F32_PEAK_TF
+                line["roofline"] = {"kernel": "LoRA linear y = x W^T + b + s (x A^T) B^T (mmgl_lora_linear_fwd)", "bound": "mfma", "achieved": round(tf, 1),
+                                    "peak": pk, "unit": "TFLOP/s", "frac": round(tf / pk, 4), "traffic": None,
+                                    "us_per_launch": round(x["ms_avg"] * 1e3, 2), "launches": x["calls"],
+                                    "algorithmic_flops_per_launch": x["flops"] / x["calls"]}
+            elif x:
                 alg = sum(2.0 * T * d * esize + 2.0 * sv * d * esize for sv in valid_keys)     # bytes per launch
                 flops = sum(4.0 * T * sv * d for sv in valid_keys)
                 sec = x["ms_avg"] * 1e-3
@@ -402,7 +442,7 @@ def main():
                 kern["mmgl_xattn_bwd"].update(bound="hbm", gbs=round(gb, 1), frac=round(gb / HBM_PEAK_GBS, 4))
             line["kernels"] = kern
             # BASELINE.json's second metric, "cross-attn TFLOPS % of peak": every mmgl_linear_* call of this step belongs to the
-            # gated cross-attention layers (projections + FFN; the frozen layers' GEMMs are library calls), so the layer-level
+            # gated cross-attention layers (projections + FFN; the frozen layers' GEMMs go through mmgl_gemm_nt), so the layer-level
             # rate is (their FLOPs + the attention core's) / (their time + the core's time), forward and backward.
             lf, lb_, xf, xb2 = (ks.get(n) for n in ("mmgl_linear_fwd", "mmgl_linear_bwd", "mmgl_xattn_fwd", "mmgl_xattn_bwd"))
             if lf and lb_ and xf and xb2:
@@ -418,7 +458,7 @@ def main():
             line["at_reference_batch"] = ref_line
         if exchange is not None:
             line["exchange"] = exchange
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and cfg["kind"] == "flamingo":
             line["cpu_baseline"] = cpu_baseline(model, cfg, lm_cfg, batch, args.cpu_samples)
         print(json.dumps(line), flush=True)
     if world > 1:

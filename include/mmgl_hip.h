@@ -243,6 +243,19 @@ int mmgl_gemm_nt(const void* x, int ldx, const void* W, int ldw, const void* bia
                  void* y, int ldy, int M, int N, int K, int act, float out_scale, int dtype, void* stream);
 int mmgl_relu_bwd(const void* dy, const void* y, void* out, size_t n, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Elementwise pieces of frozen Llama-family decoder layers (BASELINE.json config 5; the reference's fork is OPT-only,
+ * model/modelling_cross_attention.py:278-375, so these follow transformers' LlamaDecoderLayer loaded through the same HF API).
+ * mmgl_rope_inplace: rotary embedding of the first `nblk` column blocks (H heads x D each: q, then k) of buf [rows, ld], row r
+ *   at position r % T; cos_sin [T, D/2, 2] fp32 (cos, sin); rotate_half convention; backward != 0 applies the transpose
+ *   rotation (the gradient of the forward one).  In place.
+ * mmgl_swiglu_fwd: y[M,F] = silu(gate_up[:, :F]) * gate_up[:, F:]   (gate_up = one fused [gate | up] GEMM output [M, 2F]).
+ * mmgl_swiglu_bwd: dgate_up[M,2F] from dy[M,F] and the saved gate_up. */
+int mmgl_rope_inplace(void* buf, const float* cos_sin, size_t rows, int T, int H, int D, int ld, int nblk, int backward,
+                      int dtype, void* stream);
+int mmgl_swiglu_fwd(const void* gate_up, void* y, size_t M, int F, int dtype, void* stream);
+int mmgl_swiglu_bwd(const void* dy, const void* gate_up, void* dgate_up, size_t M, int F, int dtype, void* stream);
+
 int mmgl_encattn_fwd(const void* q, const void* k, const void* v, const int32_t* cu_seqlens, void* out, int nseq,
                      int H, int D, int ld_in, int ld_out, int max_len, int q_rows, int dtype, void* stream);
 int mmgl_add_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* sum_out,

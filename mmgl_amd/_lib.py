@@ -61,6 +61,9 @@ SIGNATURES = {
     "mmgl_gemm_nt_fast": (I, [I, I, I, I, I, I, I]),
     "mmgl_gemm_nt": (I, [P, I, P, I, P, P, P, P, I, I, I, I, I, F, I, P]),
     "mmgl_relu_bwd": (I, [P, P, P, Z, I, P]),
+    "mmgl_rope_inplace": (I, [P, P, Z, I, I, I, I, I, I, I, P]),
+    "mmgl_swiglu_fwd": (I, [P, P, Z, I, I, P]),
+    "mmgl_swiglu_bwd": (I, [P, P, P, Z, I, I, P]),
 }
 
 _lib = None

@@ -115,8 +115,11 @@ class MPTLearnedPositionalEmbedding(nn.Embedding):
         return F.embedding(positions, self.weight)
 
 
-def _lin(module: nn.Linear, x, **kw):
-    """nn.Linear on the HIP GEMMs: frozen parameters -> ops.frozen_linear (dgrad only, cached W^T), else ops.linear."""
+def _lin(module: nn.Module, x, **kw):
+    """nn.Linear on the HIP GEMMs: frozen parameters -> ops.frozen_linear (dgrad only, cached W^T), else ops.linear.
+    Anything that is not a plain nn.Linear (a LoRALinear wrapper, model/modelling_self_attention.py) runs its own forward."""
+    if type(module) is not nn.Linear:
+        return module(x)
     if module.weight.requires_grad or (module.bias is not None and module.bias.requires_grad):
         return ops.linear(x, module.weight, module.bias)
     return ops.frozen_linear(x, module.weight, module.bias, **kw)
@@ -171,6 +174,8 @@ class MPTAttention(nn.Module):
         """[3d, d] weight / [3d] bias = (q_proj * scaling | k_proj | v_proj) when the three projections are frozen (the
         reference freezes the whole LM outside the cross-attention layers, :731-737), else None.  A derived copy: the
         module's own parameters and state_dict stay as loaded; rebuilt when they change (load_state_dict, .bfloat16())."""
+        if any(type(m) is not nn.Linear for m in (self.q_proj, self.k_proj, self.v_proj)):
+            return None                      # adapted projections (LoRA): each one runs its own forward
         ps = (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.q_proj.bias, self.k_proj.bias, self.v_proj.bias)
         if any(p is None or p.requires_grad for p in ps):
             return None
@@ -196,10 +201,11 @@ class MPTAttention(nn.Module):
         if fused is not None:                # frozen layer: one QKV GEMM forward, one dgrad GEMM backward, no gradient adds
             o = ops.selfattn_core_fused(ops.frozen_linear(hidden_states, *fused), attention_mask, H)
         else:
-            q = ops.linear(hidden_states, self.q_proj.weight, self.q_proj.bias, out_scale=self.scaling)
-            k = ops.linear(hidden_states, self.k_proj.weight, self.k_proj.bias)
-            v = ops.linear(hidden_states, self.v_proj.weight, self.v_proj.bias)
-            o = ops.selfattn_core(q, k, v, attention_mask, H)
+            if type(self.q_proj) is nn.Linear and self.q_proj.weight.requires_grad:
+                q = ops.linear(hidden_states, self.q_proj.weight, self.q_proj.bias, out_scale=self.scaling)
+            else:
+                q = _lin(self.q_proj, hidden_states) * self.scaling
+            o = ops.selfattn_core(q, _lin(self.k_proj, hidden_states), _lin(self.v_proj, hidden_states), attention_mask, H)
         return _lin(self.out_proj, o), None, None
 
     def forward(self, hidden_states, attention_mask=None, neighbor_embeds=None, neighbor_attention_mask=None,
@@ -597,6 +603,24 @@ class MPTForCausalLM(MPTPreTrainedModel):
                                       attentions=outputs.attentions)
 
 
+def copy_opt_weights(opt_model, mpt_model):
+    """HF OPTForCausalLM -> the fork, module by module (reference :959-974); the fork's extra cross-attention layers keep
+    their fresh initialisation."""
+    src, dst = opt_model.model.decoder, mpt_model.model.decoder
+    dst.embed_tokens.load_state_dict(src.embed_tokens.state_dict())
+    dst.embed_positions.load_state_dict(src.embed_positions.state_dict())
+    if dst.project_in is not None:
+        dst.project_out.load_state_dict(src.project_out.state_dict())
+        dst.project_in.load_state_dict(src.project_in.state_dict())
+    if dst.final_layer_norm is not None:
+        dst.final_layer_norm.load_state_dict(src.final_layer_norm.state_dict())
+    for idx in range(len(src.layers)):
+        missing, unexpected = dst.layers[idx].load_state_dict(src.layers[idx].state_dict(), strict=False)
+        if missing or unexpected:
+            print(f"{idx}th layer missing_keys: {missing}, unexpected_keys: {unexpected}")
+    mpt_model.lm_head.load_state_dict(opt_model.lm_head.state_dict())
+
+
 class _PatchEmbedLinear(nn.Conv2d):
     """CLIP's patch embedding is a stride == kernel Conv2d, i.e. a GEMM over flattened patches.  MIOpen has no tuned bf16
     kernel for it here and falls back to `naive_conv_*` (8 ms / step at B=8, profiles/r1_b); the GEMM form is the same
@@ -778,22 +802,9 @@ class CrossAttentionModel(nn.Module):
         else:
             opt_config = AutoConfig.from_pretrained(args.model_name_or_path)
             opt_model = AutoModelForCausalLM.from_pretrained(args.model_name_or_path, config=opt_config)
-        mpt_config = MPTConfig(args, opt_config)
-        mpt_model = MPTForCausalLM(mpt_config)
+        mpt_model = MPTForCausalLM(MPTConfig(args, opt_config))
         if opt_model is not None:
-            src, dst = opt_model.model.decoder, mpt_model.model.decoder
-            dst.embed_tokens.load_state_dict(src.embed_tokens.state_dict())
-            dst.embed_positions.load_state_dict(src.embed_positions.state_dict())
-            if dst.project_in is not None:
-                dst.project_out.load_state_dict(src.project_out.state_dict())
-                dst.project_in.load_state_dict(src.project_in.state_dict())
-            if dst.final_layer_norm is not None:
-                dst.final_layer_norm.load_state_dict(src.final_layer_norm.state_dict())
-            for idx in range(opt_config.num_hidden_layers):
-                missing, unexpected = dst.layers[idx].load_state_dict(src.layers[idx].state_dict(), strict=False)
-                if missing or unexpected:
-                    print(f"{idx}th layer missing_keys: {missing}, unexpected_keys: {unexpected}")
-            mpt_model.lm_head.load_state_dict(opt_model.lm_head.state_dict())
+            copy_opt_weights(opt_model, mpt_model)
         self.lm = mpt_model
 
     # -------------------------------------------------------------------------------- neighbor encoders

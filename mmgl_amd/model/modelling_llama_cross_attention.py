@@ -2,11 +2,12 @@
 flamingo, 32 neighbors).  The reference's fork is OPT-specific (learned positions, LayerNorm, ReLU FFN, biases --
 model/modelling_cross_attention.py:278-375); this is the same Flamingo-style block in Llama's conventions -- RMSNorm
 pre-norm, bias-free projections, SwiGLU FFN, scalar tanh gates initialised at 0 -- inserted after every
-`neighbor_layer_wise`-th layer of a frozen HuggingFace LlamaForCausalLM through forward hooks, so nothing depends on the
-internals of the transformers implementation (RoPE, cache, masks stay HF's).  No reference counterpart exists: parity is
-UNPINNED vs MMGL; it is pinned (tests/test_llama_gpu.py) to HF Llama itself when the gates are 0 and to the CPU oracle
-(oracle/llama_ref.py) otherwise.  All trainable ops run on the HIP kernels (rms_norm, linear, xattn_core, gated_residual,
-cross_entropy).
+`neighbor_layer_wise`-th layer of a frozen LlamaForCausalLM.  The HF object is loaded through the same HF API and owns the
+weights (state-dict keys `llama.*`); its forward is replaced by the HIP path: RMSNorm kernel, ONE fused q|k|v GEMM
+(ping-pong MFMA kernel, D^-1/2 folded into the q rows), rotary embedding in place on that buffer, causal flash attention
+reading Q/K/V in place, ONE fused gate|up GEMM + SwiGLU kernel, down projection; dgrads against cached W^T copies.
+No reference counterpart exists: parity is UNPINNED vs MMGL; it is pinned (tests/test_llama_gpu.py) to HF Llama itself
+when the gates are 0 and to the CPU oracle (oracle/llama_ref.py) otherwise.
 """
 import torch
 import torch.nn as nn
@@ -43,13 +44,48 @@ class LlamaGatedCrossAttentionLayer(nn.Module):
         a = ops.linear(ops.xattn_core(q, k, v, key_valid, self.num_heads), self.o_proj.weight, None)
         h = ops.gated_residual(h, a, self.gating1, self.dropout, self.training)
         x = ops.rms_norm(h, self.post_attention_layernorm, self.eps)
-        m = F.silu(ops.linear(x, self.gate_proj.weight, None)) * ops.linear(x, self.up_proj.weight, None)
-        m = ops.linear(m, self.down_proj.weight, None)
+        # gate and up are separate trainable parameters (state-dict names of LlamaMLP); their product runs on the SwiGLU kernel
+        gu = torch.cat([ops.linear(x, self.gate_proj.weight, None), ops.linear(x, self.up_proj.weight, None)], dim=-1)
+        m = ops.linear(ops.swiglu(gu), self.down_proj.weight, None)
         return ops.gated_residual(h, m, self.gating2, self.dropout, self.training)
 
 
+class _FrozenLlamaLayer:
+    """Functional forward of one frozen HF LlamaDecoderLayer on the HIP kernels (derived fused weights are cached copies; the
+    module's own parameters and state_dict stay as loaded)."""
+
+    def __init__(self, layer, cfg):
+        self.layer, self.cfg = layer, cfg
+        self.H = cfg.num_attention_heads
+        self.D = getattr(cfg, "head_dim", None) or cfg.hidden_size // self.H
+        self._cache = None
+
+    def _fused(self):
+        at, mlp = self.layer.self_attn, self.layer.mlp
+        ps = (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight, mlp.gate_proj.weight, mlp.up_proj.weight)
+        key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+        if self._cache is None or self._cache[0] != key:
+            with torch.no_grad():
+                qkv = torch.cat([ps[0].float() * self.D ** -0.5, ps[1].float(), ps[2].float()], 0).to(ps[0].dtype).contiguous()
+                gu = torch.cat([ps[3], ps[4]], 0).contiguous()
+            self._cache = (key, qkv, gu)
+        return self._cache[1], self._cache[2]
+
+    def __call__(self, h, key_valid, cos_sin):
+        ly, eps = self.layer, self.cfg.rms_norm_eps
+        w_qkv, w_gu = self._fused()
+        x = ops.rms_norm(h, ly.input_layernorm.weight, eps)
+        qkv = ops.rope_qk_(ops.frozen_linear(x, w_qkv, None), cos_sin, self.H)
+        a = ops.frozen_linear(ops.selfattn_core_fused(qkv, key_valid, self.H), ly.self_attn.o_proj.weight, None)
+        h = ops.gated_residual(h, a)
+        x = ops.rms_norm(h, ly.post_attention_layernorm.weight, eps)
+        m = ops.frozen_linear(ops.swiglu(ops.frozen_linear(x, w_gu, None)), ly.mlp.down_proj.weight, None)
+        return ops.gated_residual(h, m)
+
+
 class LlamaNeighborLM(nn.Module):
-    """Frozen HF LlamaForCausalLM + trainable gated cross-attention layers; same call contract as MPTForCausalLM."""
+    """Frozen LlamaForCausalLM (HF loading API, weights owned by the HF module) + trainable gated cross-attention layers;
+    same call contract as MPTForCausalLM."""
 
     def __init__(self, args, llama_config=None):
         super().__init__()
@@ -61,6 +97,11 @@ class LlamaNeighborLM(nn.Module):
             self.llama = AutoModelForCausalLM.from_pretrained(args.model_name_or_path, config=cfg)
         cfg = self.llama.config
         self.config = cfg
+        if getattr(cfg, "num_key_value_heads", cfg.num_attention_heads) != cfg.num_attention_heads:
+            raise ValueError("LlamaNeighborLM: grouped-query attention (num_key_value_heads != num_attention_heads) is not implemented "
+                             "(Llama-2-7B, the BASELINE config, is multi-head)")
+        if getattr(cfg, "attention_bias", False) or getattr(cfg, "mlp_bias", False):
+            raise ValueError("LlamaNeighborLM: biased projections are not implemented")
         for p in self.llama.parameters():
             p.requires_grad = False
         n_layers = cfg.num_hidden_layers
@@ -73,38 +114,49 @@ class LlamaNeighborLM(nn.Module):
         for m in self.neighbor_layers.modules():
             if isinstance(m, nn.Linear):
                 m.weight.data.normal_(mean=0.0, std=std)
-        self._ctx = None
-        k = 0
-        for l, layer in enumerate(self.llama.model.layers):
-            if (l + 1) % self.neighbor_layer_wise == 0:
-                layer.register_forward_hook(self._make_hook(k))
-                k += 1
-
-    def _make_hook(self, k):
-        def hook(module, inputs, output):
-            if self._ctx is None:
-                return None
-            ne, valid = self._ctx
-            if torch.is_tensor(output):
-                return self.neighbor_layers[k](output, ne, valid)
-            return (self.neighbor_layers[k](output[0], ne, valid),) + tuple(output[1:])
-        return hook
+        self._frozen = [_FrozenLlamaLayer(layer, cfg) for layer in self.llama.model.layers]
+        self._rope = None
 
     def get_input_embeddings(self):
         return self.llama.get_input_embeddings()
 
-    def forward(self, input_ids=None, attention_mask=None, labels=None, neighbor_embeds=None, neighbor_attention_mask=None, **kw):
+    def _cos_sin(self, T, device):
+        """fp32 [T, D/2, 2] table of (cos, sin) for positions 0..T-1 from the HF rotary module's own inv_freq / scaling."""
+        rot = self.llama.model.rotary_emb
+        key = (T, device, rot.inv_freq.data_ptr())
+        if self._rope is None or self._rope[0] != key:
+            inv = rot.inv_freq.to(device=device, dtype=torch.float32)
+            ang = torch.arange(T, device=device, dtype=torch.float32)[:, None] * inv[None, :]
+            sc = float(getattr(rot, "attention_scaling", 1.0))
+            self._rope = (key, torch.stack([ang.cos() * sc, ang.sin() * sc], dim=-1).contiguous())
+        return self._rope[1]
+
+    def forward(self, input_ids=None, attention_mask=None, labels=None, neighbor_embeds=None, neighbor_attention_mask=None,
+                first_key_valid=False, **kw):
+        emb = self.llama.get_input_embeddings()
+        h = emb(input_ids)
+        B, T = input_ids.shape
+        if attention_mask is None:
+            attention_mask = torch.ones(B, T, dtype=torch.long, device=h.device)
+        if not first_key_valid:                   # same precondition (and device-side check) as MPTDecoder.forward
+            torch._assert_async((attention_mask[:, 0] != 0).all(), "LlamaNeighborLM: attention_mask[:, 0] must be 1 for every sample")
+        key_mask = (attention_mask != 0).to(torch.uint8).contiguous()
+        ne = valid = None
         if neighbor_embeds is not None:
             valid = neighbor_attention_mask
             if valid is None:
                 valid = torch.ones(neighbor_embeds.shape[:2], dtype=torch.uint8, device=neighbor_embeds.device)
-            emb_dtype = self.llama.get_input_embeddings().weight.dtype
-            self._ctx = (neighbor_embeds.to(emb_dtype), valid.to(torch.uint8).contiguous())
-        try:
-            hidden = self.llama.model(input_ids=input_ids, attention_mask=attention_mask, use_cache=False).last_hidden_state
-        finally:
-            self._ctx = None
-        logits = self.llama.lm_head(hidden).contiguous()
+            ne, valid = neighbor_embeds.to(emb.weight.dtype), valid.to(torch.uint8).contiguous()
+        cos_sin = self._cos_sin(T, h.device)
+        k = 0
+        for l, layer in enumerate(self._frozen):
+            h = layer(h, key_mask, cos_sin)
+            if (l + 1) % self.neighbor_layer_wise == 0:
+                if ne is not None:
+                    h = self.neighbor_layers[k](h, ne, valid)
+                k += 1
+        hidden = ops.rms_norm(h, self.llama.model.norm.weight, self.config.rms_norm_eps)
+        logits = ops.frozen_linear(hidden, self.llama.lm_head.weight, None)
         loss = None
         if labels is not None:
             nxt = torch.full_like(labels, -100)

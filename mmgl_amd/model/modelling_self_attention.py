@@ -1,7 +1,9 @@
 """Self-attention fusion wrapper: neighbor embeddings are concatenated into the LM's input sequence.
 
 Mirrors reference model/modelling_self_attention.py (constructor, forward kwargs, state-dict names of the
-wrapper-level modules).  The LM itself is the stock HuggingFace T5 / OPT; what this build owns here:
+wrapper-level modules).  T5 (config 1, CPU plumbing) is the stock HuggingFace model; a decoder-only OPT is loaded through
+the same HF API and then runs as this build's OPT fork (modelling_cross_attention.MPTForCausalLM without cross-attention
+layers, identical state-dict keys) on the HIP kernels.  What else this build owns here:
   * LoRA injection without `peft` (absent in this image, unpinned in the reference's requirements.txt:8):
     q/v projections of every attention block become LoRALinear modules whose forward/backward are the fused
     MFMA kernel `ops.lora_linear` (y = xW^T + b + (alpha/r) (xA^T)B^T), base weights frozen, `lm_head` kept
@@ -95,16 +97,24 @@ class SelfAttentionModel(nn.Module):
 
         name = args.model_name_or_path
         if "t5" in name:
-            cls = AutoModelForSeq2SeqLM
+            if lm_config is not None:
+                model = AutoModelForSeq2SeqLM.from_config(lm_config)
+            else:
+                model = AutoModelForSeq2SeqLM.from_pretrained(name, config=AutoConfig.from_pretrained(name))
         elif "opt" in name:
-            cls = AutoModelForCausalLM
+            # decoder-only: the same HF loading API (reference :66-72), the weights copied into this build's OPT fork without
+            # cross-attention layers (state-dict keys = HF's; fixture G3: fork == HF OPT), so the LM runs on the HIP path --
+            # fused-QKV / ping-pong GEMMs, causal flash attention, fused add+LayerNorm, lm_head + token cross-entropy
+            from types import SimpleNamespace
+            from .modelling_cross_attention import MPTConfig, MPTForCausalLM, copy_opt_weights
+            opt_config = lm_config if lm_config is not None else AutoConfig.from_pretrained(name)
+            hf = None if lm_config is not None else AutoModelForCausalLM.from_pretrained(name, config=opt_config)
+            plain = SimpleNamespace(neighbor_mode="raw", peft_type="none", neighbor_layer_wise=opt_config.num_hidden_layers + 1)
+            model = MPTForCausalLM(MPTConfig(plain, opt_config))
+            if hf is not None:
+                copy_opt_weights(hf, model)
         else:
             raise ValueError(f"SelfAttentionModel does not support {name}.")
-        if lm_config is not None:
-            model = cls.from_config(lm_config)
-        else:
-            config = AutoConfig.from_pretrained(name)
-            model = cls.from_pretrained(name, config=config)
 
         self.prompt_embeddings = None
         if args.peft_type == "none":
@@ -232,7 +242,9 @@ class SelfAttentionModel(nn.Module):
 
     def forward(self, input_ids, attention_mask, labels, images=None, image_positions=None, neighbor_input_ids=None,
                 neighbor_attention_mask=None, neighbor_pos_ids=None, text_locations=None, neighbor_images=None,
-                neighbor_images_pos_ids=None, image_locations=None, lpe=None, graph=None):
+                neighbor_images_pos_ids=None, image_locations=None, lpe=None, graph=None, host_meta=None):
+        # host_meta (optional, see modelling_cross_attention.host_metadata): accepted for a uniform trainer call; this wrapper
+        # encodes every neighbor slot (the concatenated sequence keeps padded slots as masked keys), so it has no use for it
         if self.neighbor_mode == "raw" and self.context in ("section_only", "text_only"):
             return self._run_lm(input_ids=input_ids, attention_mask=attention_mask, labels=labels)
 

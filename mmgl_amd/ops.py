@@ -433,7 +433,7 @@ class _LoraLinear(torch.autograd.Function):
         b = None if bias is None else bias.to(x.dtype).contiguous()
         y = torch.empty(M, N, dtype=x.dtype, device=x.device)
         xa = torch.empty(M, r, dtype=x.dtype, device=x.device)
-        _lib.call("mmgl_lora_linear_fwd", None, ptr(x2), ptr(w), ptr(b), ptr(a), ptr(bm), ptr(y), ptr(xa), M, N, K, r, scale,
+        _lib.call("mmgl_lora_linear_fwd", dict(flops=2.0 * M * N * K + 2.0 * M * r * (K + N)), ptr(x2), ptr(w), ptr(b), ptr(a), ptr(bm), ptr(y), ptr(xa), M, N, K, r, scale,
                                          dtype_code(x), stream_ptr())
         ctx.save_for_backward(x2, xa, w, a, bm)
         ctx.meta = (shape, scale, A.dtype, Bm.dtype)
@@ -450,7 +450,7 @@ class _LoraLinear(torch.autograd.Function):
         dx, dA, dB = torch.empty_like(x2), torch.empty_like(a), torch.empty_like(bm)
         dyb = torch.empty(M, r, dtype=x2.dtype, device=x2.device)
         ws = _ws(lib().mmgl_lora_linear_bwd_workspace(M, N, K, r, code), x2.device)
-        _lib.call("mmgl_lora_linear_bwd", None, ptr(dy2), ptr(x2), ptr(xa), ptr(w), ptr(a), ptr(bm), ptr(dx), ptr(dA), ptr(dB), ptr(dyb),
+        _lib.call("mmgl_lora_linear_bwd", dict(flops=2.0 * M * N * K + 6.0 * M * r * (K + N)), ptr(dy2), ptr(x2), ptr(xa), ptr(w), ptr(a), ptr(bm), ptr(dx), ptr(dA), ptr(dB), ptr(dyb),
                                          ptr(ws), ws.numel(), M, N, K, r, scale, 0, code, stream_ptr())
         return dx.view(shape), None, None, dA.to(adt), dB.to(bdt), None
 
@@ -629,13 +629,21 @@ class _FrozenLinear(torch.autograd.Function):
             x2 = x2.contiguous()
         w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
         b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
-        y = _gemm_nt_padded(x2, w.contiguous(), b, act=act)
+        kq = 8 if x.dtype == torch.bfloat16 else 4
+        if K % kq == 0 and N % 8 == 0:
+            # the output is allocated in its final shape and returned as is (not a view made inside this Function): consumers
+            # such as the in-place rotary embedding may then modify it
+            out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+            y = gemm_nt(x2, w.contiguous(), b, act=act, out=out.view(-1, N))
+        else:
+            out = None
+            y = _gemm_nt_padded(x2, w.contiguous(), b, act=act)
         # premasked: the consumer folds this layer's ReLU backward into its own dgrad (mask_dx there): differentiate as a plain
         # linear and keep nothing.  mask_dx: x2 is a ReLU output whose backward rides in this layer's dgrad epilogue.
         ctx.save_for_backward(weight, y if (act == 1 and not premasked) else None, x2 if mask_dx else None)
         ctx.act = 0 if premasked else act
         ctx.xshape = x.shape
-        return y.view(*x.shape[:-1], N)
+        return out if out is not None else y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
@@ -681,6 +689,75 @@ def frozen_linear(x, weight, bias, relu=False, mask_dx=False, bwd_premasked=Fals
 
 def frozen_linear_relu(x, weight, bias):
     return frozen_linear(x, weight, bias, relu=True)
+
+
+# ------------------------------------------------------------------------------------------ Llama-family elementwise ops
+class _RopeQK(torch.autograd.Function):
+    """Rotary embedding of the q and k blocks of a fused-QKV buffer [B, T, 3*H*D], in place (the buffer is a fresh GEMM output)."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos_sin, num_heads):
+        require_cuda(qkv, cos_sin)
+        B, T, d3 = qkv.shape
+        D = d3 // 3 // num_heads
+        if not qkv.is_contiguous():
+            raise ValueError("rope_qk_: qkv must be contiguous")
+        _lib.call("mmgl_rope_inplace", dict(bytes=2.0 * B * T * (2 * d3 // 3) * qkv.element_size()), ptr(qkv), ptr(cos_sin), B * T, T, num_heads, D, d3, 2, 0,
+                  dtype_code(qkv), stream_ptr())
+        ctx.mark_dirty(qkv)
+        ctx.save_for_backward(cos_sin)
+        ctx.meta = (T, num_heads, D)
+        return qkv
+
+    @staticmethod
+    def backward(ctx, dqkv):
+        (cos_sin,) = ctx.saved_tensors
+        T, H, D = ctx.meta
+        dqkv = dqkv.contiguous()
+        rows = dqkv.numel() // dqkv.shape[-1]
+        _lib.call("mmgl_rope_inplace", dict(bytes=2.0 * rows * (2 * dqkv.shape[-1] // 3) * dqkv.element_size()), ptr(dqkv), ptr(cos_sin), rows, T, H, D,
+                  dqkv.shape[-1], 2, 1, dtype_code(dqkv), stream_ptr())
+        return dqkv, None, None
+
+
+def rope_qk_(qkv, cos_sin, num_heads):
+    """In-place rotary position embedding of the q and k thirds of qkv [B, T, 3*H*D] (transformers' rotate_half convention,
+    position = index along T).  cos_sin: fp32 [T, D/2, 2]."""
+    if qkv.dim() != 3 or qkv.shape[2] % (3 * num_heads):
+        raise ValueError(f"rope_qk_: qkv{tuple(qkv.shape)} is not [B, T, 3*H*D] for H={num_heads}")
+    D = qkv.shape[2] // 3 // num_heads
+    if cos_sin.dtype != torch.float32 or tuple(cos_sin.shape) != (qkv.shape[1], D // 2, 2):
+        raise ValueError(f"rope_qk_: cos_sin must be fp32 [T={qkv.shape[1]}, D/2={D // 2}, 2], got {cos_sin.dtype} {tuple(cos_sin.shape)}")
+    return _RopeQK.apply(qkv, cos_sin.contiguous(), num_heads)
+
+
+class _SwiGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gu):
+        require_cuda(gu)
+        F2 = gu.shape[-1]
+        g2 = gu.contiguous().view(-1, F2)
+        y = torch.empty(g2.shape[0], F2 // 2, dtype=gu.dtype, device=gu.device)
+        _lib.call("mmgl_swiglu_fwd", dict(bytes=1.5 * g2.numel() * g2.element_size()), ptr(g2), ptr(y), g2.shape[0], F2 // 2, dtype_code(g2), stream_ptr())
+        ctx.save_for_backward(g2)
+        ctx.shape = gu.shape
+        return y.view(*gu.shape[:-1], F2 // 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (g2,) = ctx.saved_tensors
+        M, F2 = g2.shape
+        dy2 = dy.contiguous().view(M, F2 // 2)
+        dgu = torch.empty_like(g2)
+        _lib.call("mmgl_swiglu_bwd", dict(bytes=2.5 * g2.numel() * g2.element_size()), ptr(dy2), ptr(g2), ptr(dgu), M, F2 // 2, dtype_code(g2), stream_ptr())
+        return dgu.view(ctx.shape)
+
+
+def swiglu(gate_up):
+    """silu(gate_up[..., :F]) * gate_up[..., F:] over one fused [gate | up] projection output (LlamaMLP)."""
+    if gate_up.shape[-1] % 2:
+        raise ValueError("swiglu: last dim must be 2*F")
+    return _SwiGLU.apply(gate_up)
 
 
 # ------------------------------------------------------------------------------------------ frozen encoders (forward only)

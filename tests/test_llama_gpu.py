@@ -89,3 +89,82 @@ def test_cross_attention_model_selects_llama_variant():
     out.loss.backward()
     assert torch.isfinite(out.loss)
     assert all(p.grad is not None for n, p in w.named_parameters() if p.requires_grad and "neighbor_layers" in n)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("B,T,H,D", [(2, 24, 4, 16), (1, 2176, 8, 128)])
+def test_rope_qk_matches_transformers_rotate_half(B, T, H, D, dtype, tol):
+    """mmgl_rope_inplace on the q / k thirds of a fused-QKV buffer == transformers' apply_rotary_pos_emb (rotate_half), forward
+    and gradient; the v third is untouched."""
+    from transformers.models.llama.modeling_llama import apply_rotary_pos_emb
+    from mmgl_amd import ops
+    g = torch.Generator().manual_seed(T)
+    d = H * D
+    qkv = torch.randn(B, T, 3 * d, generator=g)
+    w = torch.randn(B, T, 3 * d, generator=g)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(T).float()[:, None] * inv[None]
+    cos_sin = torch.stack([ang.cos(), ang.sin()], -1)
+    x = qkv.to(dtype).cuda().requires_grad_()
+    y = ops.rope_qk_(x * 1.0, cos_sin.cuda(), H)            # (x * 1.0: a fresh buffer, as the GEMM output is)
+    (y.float() * w.cuda()).sum().backward()
+    xr = x.detach().float().cpu().requires_grad_()
+    q, k, v = (xr[..., i * d:(i + 1) * d].view(B, T, H, D).transpose(1, 2) for i in range(3))
+    cos = torch.cat([ang.cos(), ang.cos()], -1)[None]
+    sin = torch.cat([ang.sin(), ang.sin()], -1)[None]
+    qe, ke = apply_rotary_pos_emb(q, k, cos, sin)
+    yr = torch.cat([t.transpose(1, 2).reshape(B, T, d) for t in (qe, ke, v)], -1)
+    (yr * w).sum().backward()
+    assert_close(y.float(), yr, tol, "rope fwd")
+    assert_close(x.grad.float(), xr.grad, tol, "rope bwd")
+    assert torch.equal(y[..., 2 * d:].float().cpu(), x.detach()[..., 2 * d:].float().cpu())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("M,F", [(50, 128), (2176, 11008)])
+def test_swiglu_fwd_bwd(M, F, dtype, tol):
+    from mmgl_amd import ops
+    g = torch.Generator().manual_seed(F)
+    gu = torch.randn(M, 2 * F, generator=g)
+    w = torch.randn(M, F, generator=g)
+    x = gu.to(dtype).cuda().requires_grad_()
+    y = ops.swiglu(x)
+    (y.float() * w.cuda()).sum().backward()
+    xr = x.detach().float().cpu().requires_grad_()
+    yr = torch.nn.functional.silu(xr[:, :F]) * xr[:, F:]
+    (yr * w).sum().backward()
+    assert_close(y.float(), yr, tol, "swiglu fwd")
+    assert_close(x.grad.float(), xr.grad, tol, "swiglu bwd")
+
+
+def test_llama_config5_dims_one_layer_bf16():
+    """One frozen layer + one gated block at Llama-2-7B's dims (d 4096, 32 heads x 128, ffn 11008), T = 2176, S = 128, bf16:
+    the frozen path against HF's own LlamaDecoderLayer arithmetic in fp32 (gates 0), then gradients flow with gates != 0."""
+    from transformers import LlamaConfig
+    from mmgl_amd.model.modelling_llama_cross_attention import LlamaNeighborLM
+    cfg = LlamaConfig(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=1, num_attention_heads=32,
+                      num_key_value_heads=32, max_position_embeddings=4096, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    torch.manual_seed(0)
+    lm = LlamaNeighborLM(mpt_args(model_name_or_path="llama-2-7b", neighbor_layer_wise=1), cfg)
+    B, T, S = 1, 2176, 128
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(3, 32000, (B, T), generator=g)
+    am = torch.ones(B, T, dtype=torch.long)
+    am[0, 1500:2048] = 0
+    ne = torch.randn(B, S, 4096, generator=g) * 0.5
+    valid = torch.ones(B, S, dtype=torch.bool)
+    valid[0, 100:] = False
+    lm = lm.bfloat16().cuda().eval()
+    with torch.no_grad():
+        got = lm(input_ids=ids.cuda(), attention_mask=am.cuda(), neighbor_embeds=ne.cuda(), neighbor_attention_mask=valid.cuda()).logits
+        want = lm.llama.float()(input_ids=ids.cuda(), attention_mask=am.cuda()).logits          # HF forward, fp32, same (bf16-rounded) weights
+    keep = am.bool().cuda()
+    assert_close(got.float()[keep], want[keep], 3e-2, "config-5 dims: logits vs HF Llama (valid positions)")
+    lm.llama.bfloat16()
+    with torch.no_grad():
+        lm.neighbor_layers[0].gating1.fill_(0.5)
+        lm.neighbor_layers[0].gating2.fill_(0.3)
+    out = lm(input_ids=ids.cuda(), attention_mask=am.cuda(), labels=ids.cuda(), neighbor_embeds=ne.cuda().bfloat16(), neighbor_attention_mask=valid.cuda())
+    out.loss.backward()
+    for n, p in lm.neighbor_layers.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, n

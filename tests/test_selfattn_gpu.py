@@ -12,6 +12,7 @@ CASES = [  # B, H, T, D
     (2, 3, 100, 32),       # ragged T
     (3, 4, 640, 64),       # OPT shape
     (1, 2, 1000, 128),     # Llama head dim, T not a tile multiple
+    (1, 4, 2176, 128),     # BASELINE config 5: Llama-2-7B head dim at T = 2048 + 128
 ]
 
 
