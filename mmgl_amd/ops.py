@@ -456,7 +456,18 @@ class _LoraLinear(torch.autograd.Function):
 
 
 def lora_linear(x, weight, bias, lora_A, lora_B, scale):
-    """x W^T + b + scale * (x A^T) B^T with a frozen base weight (peft LoRA semantics, lora_dropout = 0)."""
+    """x W^T + b + scale * (x A^T) B^T with a frozen base weight (peft LoRA semantics, lora_dropout = 0).
+    Large bf16 shapes: the base product runs on the persistent ping-pong GEMM with the low-rank update
+    delta = (x A^T)(scale B)^T -- two skinny, HBM-bound GEMMs -- added in its epilogue; backward = the frozen dgrad GEMM plus
+    the four skinny products autograd derives from the same pieces.  Everything else: one fused kernel (mmgl_lora_linear_*)
+    that carries the rank-r term as a second operand pair in the same accumulators."""
+    M = x.numel() // x.shape[-1]
+    N, K = weight.shape
+    if (not weight.requires_grad and (bias is None or not bias.requires_grad) and x.is_cuda
+            and lib().mmgl_gemm_nt_fast(M, N, K, K, K, N, dtype_code(x))):
+        xa = linear(x, lora_A)                                     # [.., r]
+        delta = linear(xa, lora_B, out_scale=scale)                # [.., N]
+        return frozen_linear(x, weight, bias, residual=delta)
     return _LoraLinear.apply(x, weight, bias, lora_A, lora_B, float(scale))
 
 
@@ -621,7 +632,7 @@ def _gemm_nt_padded(x2, w, bias=None, zmask=None, act=0, K=None):
 
 class _FrozenLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act, mask_dx, premasked):
+    def forward(ctx, x, weight, bias, act, mask_dx, premasked, residual=None):
         require_cuda(x, weight)
         K, N = weight.shape[1], weight.shape[0]
         x2 = x.reshape(-1, K)
@@ -634,10 +645,14 @@ class _FrozenLinear(torch.autograd.Function):
             # the output is allocated in its final shape and returned as is (not a view made inside this Function): consumers
             # such as the in-place rotary embedding may then modify it
             out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
-            y = gemm_nt(x2, w.contiguous(), b, act=act, out=out.view(-1, N))
+            r2 = None if residual is None else residual.reshape(-1, N).contiguous()
+            y = gemm_nt(x2, w.contiguous(), b, residual=r2, act=act, out=out.view(-1, N))
         else:
             out = None
             y = _gemm_nt_padded(x2, w.contiguous(), b, act=act)
+            if residual is not None:
+                y = y + residual.reshape(-1, N)
+        ctx.has_resid = residual is not None
         # premasked: the consumer folds this layer's ReLU backward into its own dgrad (mask_dx there): differentiate as a plain
         # linear and keep nothing.  mask_dx: x2 is a ReLU output whose backward rides in this layer's dgrad epilogue.
         ctx.save_for_backward(weight, y if (act == 1 and not premasked) else None, x2 if mask_dx else None)
@@ -666,13 +681,14 @@ class _FrozenLinear(torch.autograd.Function):
         if kk != N and not lib().mmgl_gemm_nt_fast(g.shape[0], K, kk, N, kk, K, dtype_code(g)):
             wt, kk = wt[:, :N].contiguous(), N                # shape not on the fast path: dense operands
         dx = _gemm_nt_padded(g, wt, zmask=xmask, K=kk)
-        return dx.view(ctx.xshape), None, None, None, None, None
+        return dx.view(ctx.xshape), None, None, None, None, None, (dy if ctx.has_resid else None)
 
 
-def frozen_linear(x, weight, bias, relu=False, mask_dx=False, bwd_premasked=False, act=None):
+def frozen_linear(x, weight, bias, relu=False, mask_dx=False, bwd_premasked=False, act=None, residual=None):
     """act(x W^T + b) for a FROZEN nn.Linear (reference :194-199, :273, :352-355 inside the frozen LM layers, lm_head :826).
     mask_dx / bwd_premasked: as in `linear` -- `h = frozen_linear(x, W1, b1, relu=True, bwd_premasked=True);
-    y = frozen_linear(h, W2, b2, mask_dx=True)` puts fc1's ReLU backward into the epilogue of fc2's dgrad GEMM."""
+    y = frozen_linear(h, W2, b2, mask_dx=True)` puts fc1's ReLU backward into the epilogue of fc2's dgrad GEMM.
+    residual: a differentiable [..., out_features] tensor added in the GEMM epilogue (the LoRA update of an adapted projection)."""
     if weight.requires_grad or (bias is not None and bias.requires_grad):
         raise ValueError("frozen_linear: weight and bias must be frozen (requires_grad=False)")
     if x.shape[-1] != weight.shape[1]:
@@ -684,7 +700,9 @@ def frozen_linear(x, weight, bias, relu=False, mask_dx=False, bwd_premasked=Fals
         raise ValueError("frozen_linear: GELU epilogues are forward-only (frozen encoders); use relu / none under autograd")
     if bwd_premasked and code != 1:
         raise ValueError("frozen_linear: bwd_premasked needs the ReLU epilogue")
-    return _FrozenLinear.apply(x, weight, bias, code, bool(mask_dx), bool(bwd_premasked))
+    if residual is not None and (code or residual.shape[:-1] != x.shape[:-1] or residual.shape[-1] != weight.shape[0]):
+        raise ValueError("frozen_linear: `residual` ([..., out_features], added in the GEMM epilogue) goes with no activation")
+    return _FrozenLinear.apply(x, weight, bias, code, bool(mask_dx), bool(bwd_premasked), residual)
 
 
 def frozen_linear_relu(x, weight, bias):
