@@ -81,6 +81,16 @@ __device__ __forceinline__ int p8_lane() {
 #define P8_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define P8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define P8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// after the barrier that opens an MFMA cluster: wait for every fragment (1) or let hipcc's own counted lgkmcnt waits release the
+// MFMAs fragment by fragment (0: the first MFMAs start while the last ds_reads are still in flight)
+#ifndef P8_WAIT_ALL_FRAGS
+#define P8_WAIT_ALL_FRAGS 0
+#endif
+#if P8_WAIT_ALL_FRAGS
+#define P8_LGKM_PHASE() P8_LGKM0()
+#else
+#define P8_LGKM_PHASE() (void)0
+#endif
 
 template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel(P8Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -288,7 +298,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         }                                                                                        \
         P8_VMCNT(10);                                                                            \
         P8_BARRIER();                                                                            \
-        P8_LGKM0();                                                                              \
+        P8_LGKM_PHASE();                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         __builtin_amdgcn_s_setprio(1);                                                           \
         MMA;                                                                                     \

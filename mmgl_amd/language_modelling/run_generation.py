@@ -278,6 +278,9 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
     for i, batch in enumerate(train_loader):
         data_time.update(time.time() - end)
         extra = _host_meta(model, batch)               # read off the batch while it is still in host memory
+        sliced = bool(extra) and args.decoder_only
+        if sliced:                                     # the running summary loss below reads positions L_in .. T-2 only: the training
+            extra["logits_slice"] = slice(args.max_input_length, -1)       # step then never builds the [B, T, V] logits
         batch = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
         boundary = ((i + 1) % accum == 0) or (i == args.steps_per_epoch - 1)
         engine.sync = boundary                         # gradients cross xGMI once per optimizer step
@@ -287,7 +290,10 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
         forward_time.update(time.time() - forward_start)
         loss = outputs.loss
         if args.decoder_only:
-            lg, lb = _summary_slices(args, outputs.logits.detach(), batch["labels"])
+            if sliced:
+                lg, lb = outputs.logits.detach(), batch["labels"][..., (args.max_input_length + 1):]
+            else:
+                lg, lb = _summary_slices(args, outputs.logits.detach(), batch["labels"])
             summary_loss = nn.functional.cross_entropy(lg.reshape(-1, lg.size(-1)).float(), lb.reshape(-1), ignore_index=pad_id)
             losses.update(summary_loss.item(), batch["input_ids"].size(0))
         else:

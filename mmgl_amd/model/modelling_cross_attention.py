@@ -546,6 +546,33 @@ def mark_only_peft_as_trainable(model):
                 p.requires_grad = True
 
 
+def lm_head_loss_and_logits(module, lm_head, hidden, next_labels, return_logits=None, logits_slice=None):
+    """(loss, logits) of a causal-LM head (reference :826-836).  A TRAINING step with a frozen head (every peft mode of the
+    reference: the head is tied to the frozen embedding) runs ops.lm_head_cross_entropy -- lm_head and the token cross-entropy
+    fused, the [B, T, V] logits and their gradient (4.1 GB each at B=64) are never built -- and returns logits = None, or, with
+    `logits_slice` (a slice along T), the logits of just those positions without gradient: what the trainer's running summary
+    loss reads (run_generation.py:473-480 looks at positions max_input_length..T-1 only).  `return_logits=True` forces the
+    reference's contract (full logits, separate cross-entropy kernel); the default is that contract whenever the fused path
+    does not apply (eval, no labels, trainable head, grad disabled)."""
+    frozen = type(lm_head) is nn.Linear and not lm_head.weight.requires_grad and lm_head.bias is None
+    fuse = (next_labels is not None and module.training and torch.is_grad_enabled() and frozen and hidden.is_cuda
+            and not return_logits)
+    if fuse:
+        loss = ops.lm_head_cross_entropy(hidden, lm_head.weight, next_labels)
+        logits = None
+        if logits_slice is not None:
+            with torch.no_grad():
+                logits = _lin(lm_head, hidden.detach()[:, logits_slice].contiguous())
+        return loss, logits
+    logits = _lin(lm_head, hidden)
+    loss = None
+    if next_labels is not None:
+        loss = ops.cross_entropy(logits.view(-1, logits.shape[-1]), next_labels.view(-1))
+    if logits_slice is not None:
+        logits = logits[:, logits_slice]
+    return loss, logits
+
+
 class MPTForCausalLM(MPTPreTrainedModel):
     _tied_weights_keys = ["lm_head.weight"]
 
@@ -580,22 +607,23 @@ class MPTForCausalLM(MPTPreTrainedModel):
 
     def forward(self, input_ids=None, attention_mask=None, head_mask=None, past_key_values=None, inputs_embeds=None,
                 labels=None, neighbor_embeds=None, neighbor_attention_mask=None, use_cache=None, output_attentions=None,
-                output_hidden_states=None, return_dict=None, first_key_valid=False):
+                output_hidden_states=None, return_dict=None, first_key_valid=False, return_logits=None, logits_slice=None):
+        """return_logits / logits_slice: see lm_head_loss_and_logits (training steps never build the [B, T, V] logits unless asked)."""
         return_dict = True if return_dict is None else return_dict
         outputs = self.model.decoder(input_ids=input_ids, attention_mask=attention_mask, head_mask=head_mask,
                                      past_key_values=past_key_values, inputs_embeds=inputs_embeds,
                                      neighbor_embeds=neighbor_embeds, neighbor_attention_mask=neighbor_attention_mask,
                                      use_cache=use_cache, output_attentions=output_attentions,
                                      output_hidden_states=output_hidden_states, return_dict=True, first_key_valid=first_key_valid)
-        logits = _lin(self.lm_head, outputs.last_hidden_state)
-        loss = None
+        hidden = outputs.last_hidden_state
+        nxt = None
         if labels is not None:
             # tokens < n predict n (:831-836).  Instead of copying the [B,T-1,V] slice, every row is scored against the
             # next label and the last position of each sample is ignored: the same mean over B*(T-1) rows.
-            labels = labels.to(logits.device)
+            labels = labels.to(hidden.device)
             nxt = torch.full_like(labels, -100)
             nxt[:, :-1] = labels[:, 1:]
-            loss = ops.cross_entropy(logits.view(-1, logits.shape[-1]), nxt.view(-1))
+        loss, logits = lm_head_loss_and_logits(self, self.lm_head, hidden, nxt, return_logits, logits_slice)
         if not return_dict:
             output = (logits,) + tuple(v for v in (outputs.hidden_states, outputs.attentions) if v is not None)
             return (loss,) + output if loss is not None else output
@@ -884,9 +912,10 @@ class CrossAttentionModel(nn.Module):
 
     def forward(self, input_ids, attention_mask, labels, images=None, image_positions=None, neighbor_input_ids=None,
                 neighbor_attention_mask=None, neighbor_pos_ids=None, text_locations=None, neighbor_images=None,
-                neighbor_images_pos_ids=None, image_locations=None, host_meta=None):
+                neighbor_images_pos_ids=None, image_locations=None, host_meta=None, return_logits=None, logits_slice=None):
         """`host_meta` (optional, not in the reference's signature): the dict of `host_metadata(batch)` computed by the collate /
-        trainer while the batch was still in host memory; with it the step has no device->host synchronisation."""
+        trainer while the batch was still in host memory; with it the step has no device->host synchronisation.
+        `return_logits` / `logits_slice`: see lm_head_loss_and_logits -- a training step does not build the [B, T, V] logits."""
         if self.neighbor_mode == "raw" or self.context == "section_only":
             neighbor_embeds, key_valid = None, None          # sanity path: the plain OPT (:1068-1071)
         elif self.cross_path and self.context == "text_only":
@@ -902,4 +931,5 @@ class CrossAttentionModel(nn.Module):
         else:
             raise ValueError(f"Neighbor mode: {self.neighbor_mode} and context: {self.context} are not supported.")
         return self.lm(input_ids=input_ids, attention_mask=attention_mask, labels=labels, neighbor_embeds=neighbor_embeds,
-                       neighbor_attention_mask=key_valid, first_key_valid=bool(host_meta and host_meta.get("first_key_valid")))
+                       neighbor_attention_mask=key_valid, first_key_valid=bool(host_meta and host_meta.get("first_key_valid")),
+                       return_logits=return_logits, logits_slice=logits_slice)

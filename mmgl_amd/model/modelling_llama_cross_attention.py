@@ -132,7 +132,7 @@ class LlamaNeighborLM(nn.Module):
         return self._rope[1]
 
     def forward(self, input_ids=None, attention_mask=None, labels=None, neighbor_embeds=None, neighbor_attention_mask=None,
-                first_key_valid=False, **kw):
+                first_key_valid=False, return_logits=None, logits_slice=None, **kw):
         emb = self.llama.get_input_embeddings()
         h = emb(input_ids)
         B, T = input_ids.shape
@@ -156,10 +156,10 @@ class LlamaNeighborLM(nn.Module):
                     h = self.neighbor_layers[k](h, ne, valid)
                 k += 1
         hidden = ops.rms_norm(h, self.llama.model.norm.weight, self.config.rms_norm_eps)
-        logits = ops.frozen_linear(hidden, self.llama.lm_head.weight, None)
-        loss = None
+        nxt = None
         if labels is not None:
             nxt = torch.full_like(labels, -100)
             nxt[:, :-1] = labels[:, 1:]
-            loss = ops.cross_entropy(logits.view(-1, logits.shape[-1]), nxt.view(-1))
+        from .modelling_cross_attention import lm_head_loss_and_logits
+        loss, logits = lm_head_loss_and_logits(self, self.llama.lm_head, hidden, nxt, return_logits, logits_slice)
         return CausalLMOutputWithPast(loss=loss, logits=logits)

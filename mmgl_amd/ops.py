@@ -546,6 +546,67 @@ def cross_entropy(logits, labels, ignore_index=-100):
     return _CrossEntropy.apply(logits, labels, int(ignore_index))
 
 
+class _LMHeadCrossEntropy(torch.autograd.Function):
+    """Token cross-entropy of lm_head(hidden) WITHOUT the [rows, V] logits / dlogits tensors (4.1 GB each at B=64): rows are
+    processed in chunks through one scratch buffer -- logits chunk = GEMM, CE statistics, dlogits chunk in place, d hidden
+    chunk = GEMM against the cached W^T -- all in the FORWARD pass for a unit upstream gradient; backward scales d hidden by
+    the incoming scalar.  Same FLOPs as the unfused path (no recomputation).  The head is frozen (tied to the frozen
+    embedding in every peft mode of the reference, :731-737)."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, labels, ignore_index, chunk_rows):
+        require_cuda(hidden, weight, labels)
+        V, d = weight.shape
+        h2 = hidden.reshape(-1, d)
+        if not h2.is_contiguous():
+            h2 = h2.contiguous()
+        M = h2.shape[0]
+        lab = labels.reshape(-1).contiguous()
+        dev = h2.device
+        w = weight if weight.dtype == h2.dtype else weight.to(h2.dtype)
+        count = (lab != ignore_index).sum().to(torch.float32).reshape(1)
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        dh = torch.empty_like(h2)
+        chunk = min(M, int(chunk_rows))
+        scratch = torch.empty(chunk, V, dtype=h2.dtype, device=dev)
+        row_lse = torch.empty(chunk, dtype=torch.float32, device=dev)
+        row_loss = torch.empty(chunk, dtype=torch.float32, device=dev)
+        part = torch.empty(2, dtype=torch.float32, device=dev)
+        code = dtype_code(h2)
+        es = h2.element_size()
+        for r0 in range(0, M, chunk):
+            r1 = min(M, r0 + chunk)
+            n = r1 - r0
+            lg = scratch[:n]
+            gemm_nt(h2[r0:r1], w.contiguous(), out=lg)
+            _lib.call("mmgl_cross_entropy_fwd", dict(bytes=1.0 * n * V * es), ptr(lg), ptr(lab[r0:r1]), ptr(row_lse), ptr(row_loss), ptr(part[0:1]),
+                      ptr(part[1:2]), n, V, ignore_index, code, stream_ptr())
+            loss_sum += part[0:1]
+            _lib.call("mmgl_cross_entropy_bwd", dict(bytes=2.0 * n * V * es), ptr(lg), ptr(lab[r0:r1]), ptr(row_lse), ptr(count), ptr(one), ptr(lg), n, V,
+                      ignore_index, code, stream_ptr())
+            frozen_dgrad(lg, weight, out=dh[r0:r1])
+        ctx.save_for_backward(dh)
+        ctx.shape = hidden.shape
+        return (loss_sum / count.clamp_min(1.0)).reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dh,) = ctx.saved_tensors
+        return (dh * dloss.to(dh.dtype)).view(ctx.shape), None, None, None, None
+
+
+def lm_head_cross_entropy(hidden, weight, labels, ignore_index=-100, chunk_rows=8192):
+    """Mean token cross-entropy of `hidden @ weight.T` against `labels` (nn.CrossEntropyLoss semantics) with a FROZEN head,
+    never materialising the logits (reference :826-836 builds [B, T, V] logits, the shifted copy and their gradients).
+    hidden [..., d], weight [V, d], labels [...] int64 (already shifted).  fp32 scalar."""
+    if weight.requires_grad:
+        raise ValueError("lm_head_cross_entropy: the head must be frozen (use lm_head + cross_entropy for a trainable head)")
+    if hidden.shape[:-1] != labels.shape or hidden.shape[-1] != weight.shape[1]:
+        raise ValueError(f"lm_head_cross_entropy: shapes hidden{tuple(hidden.shape)} weight{tuple(weight.shape)} labels{tuple(labels.shape)}")
+    return _LMHeadCrossEntropy.apply(hidden, weight, labels, int(ignore_index), int(chunk_rows))
+
+
 def position_ids(attention_mask):
     """cumsum(mask) * mask - 1 + 2  (reference MPTLearnedPositionalEmbedding :135-145)."""
     require_cuda(attention_mask)
@@ -630,6 +691,25 @@ def _gemm_nt_padded(x2, w, bias=None, zmask=None, act=0, K=None):
     return y[:, :N].contiguous() if pn else y
 
 
+def frozen_dgrad(g, weight, zmask=None, out=None):
+    """dx[M,K] = g[M,N] @ W[N,K] for a frozen W  ==  an NT GEMM against the cached W^T [K, Npad].  The contraction length is
+    padded to a multiple of 128 with zero columns of W^T (lm_head: N = vocab = 50272) and g is read with its own row stride.
+    No autograd."""
+    N, K = weight.shape
+    pad = 128 if (g.dtype == torch.bfloat16 and N % 128) else 1
+    wt = _transposed(weight, pad) if weight.dtype == g.dtype else weight.detach().to(g.dtype).t().contiguous()
+    kk = wt.shape[1]
+    if kk != N and not lib().mmgl_gemm_nt_fast(g.shape[0], K, kk, g.stride(0), kk, K, dtype_code(g)):
+        wt, kk = wt[:, :N].contiguous(), N                # shape not on the fast path: dense operands
+    if out is not None and kk % (8 if g.dtype == torch.bfloat16 else 4) == 0 and K % 8 == 0:
+        return gemm_nt(g, wt, zmask=zmask, K=kk, out=out)
+    dx = _gemm_nt_padded(g, wt, zmask=zmask, K=kk)
+    if out is not None:
+        out.copy_(dx)
+        return out
+    return dx
+
+
 class _FrozenLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, mask_dx, premasked, residual=None):
@@ -673,14 +753,7 @@ class _FrozenLinear(torch.autograd.Function):
             g = gm
         elif ctx.act:
             raise RuntimeError("frozen_linear: only the ReLU epilogue is differentiable")
-        # dx[M,K] = g[M,N] @ W[N,K]  ==  NT GEMM against W^T [K, Npad]; the contraction length is padded to a multiple of 128
-        # with zero columns of W^T (lm_head: N = vocab = 50272), g is read with its own row stride
-        pad = 128 if (g.dtype == torch.bfloat16 and N % 128) else 1
-        wt = _transposed(weight, pad) if weight.dtype == g.dtype else weight.detach().to(g.dtype).t().contiguous()
-        kk = wt.shape[1]
-        if kk != N and not lib().mmgl_gemm_nt_fast(g.shape[0], K, kk, N, kk, K, dtype_code(g)):
-            wt, kk = wt[:, :N].contiguous(), N                # shape not on the fast path: dense operands
-        dx = _gemm_nt_padded(g, wt, zmask=xmask, K=kk)
+        dx = frozen_dgrad(g, weight, zmask=xmask)
         return dx.view(ctx.xshape), None, None, None, None, None, (dy if ctx.has_resid else None)
 
 

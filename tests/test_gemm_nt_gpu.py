@@ -123,3 +123,55 @@ def test_frozen_lm_head_padded_dgrad():
     want_dx = dl.float() @ W.float()
     assert (y.float() - want_y).abs().max().item() <= 2e-2 * want_y.abs().max().item() + 1e-2
     assert (x.grad.float() - want_dx).abs().max().item() <= 2e-2 * want_dx.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("M,d,V,chunk", [(40960, 2048, 50272, 8192), (2176 * 4, 4096, 32000, 4096), (100, 64, 128, 32)])
+def test_lm_head_cross_entropy_fused_equals_unfused(M, d, V, chunk):
+    """lm_head + token cross-entropy without the [rows, V] logits (reference :826-836) against the unfused pair (frozen_linear +
+    mmgl_cross_entropy): loss to 1e-3, d hidden to 2e-2 (bf16), including ignored rows and an upstream gradient != 1."""
+    from mmgl_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(V)
+    h = (torch.randn(M, d, device="cuda", generator=g) * 0.5).bfloat16()
+    W = (torch.randn(V, d, device="cuda", generator=g) * d ** -0.5).bfloat16()
+    lab = torch.randint(0, V, (M,), device="cuda", generator=g)
+    lab[::7] = -100
+    h1 = h.clone().requires_grad_()
+    loss1 = ops.lm_head_cross_entropy(h1, W, lab, chunk_rows=chunk)
+    (loss1 * 0.37).backward()
+    h2 = h.clone().requires_grad_()
+    loss2 = ops.cross_entropy(ops.frozen_linear(h2, W, None), lab)
+    (loss2 * 0.37).backward()
+    assert abs(float(loss1) - float(loss2)) <= 1e-3 * abs(float(loss2))
+    assert (h1.grad.float() - h2.grad.float()).abs().max().item() <= 2e-2 * h2.grad.float().abs().max().item()
+    ref = torch.nn.functional.cross_entropy(h.float() @ W.float().t(), lab, ignore_index=-100) if M <= 10000 else None
+    if ref is not None:
+        assert abs(float(loss1) - float(ref)) <= 5e-3 * abs(float(ref))
+
+
+def test_training_step_does_not_build_logits():
+    """MPTForCausalLM in train mode with a frozen head returns loss without .logits (peak memory stays below one full logits
+    tensor); `logits_slice` returns just those positions; eval keeps the reference contract."""
+    from helpers import mpt_args, tiny_opt_config
+    from mmgl_amd.model.modelling_cross_attention import MPTConfig, MPTForCausalLM
+    torch.manual_seed(0)
+    lm = MPTForCausalLM(MPTConfig(mpt_args(), tiny_opt_config(dropout=0.0))).cuda()
+    ids = torch.randint(3, 128, (2, 24), device="cuda")
+    am = torch.ones_like(ids)
+    ne = torch.randn(2, 6, 64, device="cuda")
+    nv = torch.ones(2, 6, dtype=torch.bool, device="cuda")
+    kw = dict(input_ids=ids, attention_mask=am, labels=ids, neighbor_embeds=ne, neighbor_attention_mask=nv)
+    lm.train()
+    o = lm(**kw)
+    assert o.logits is None and o.loss.requires_grad
+    o.loss.backward()
+    assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for n, p in lm.named_parameters() if "neighbor_layers" in n)
+    o2 = lm(**kw, logits_slice=slice(16, -1))
+    lm.eval()
+    with torch.no_grad():
+        oe = lm(**kw)
+    assert oe.logits.shape == (2, 24, 128) and o2.logits.shape == (2, 7, 128)
+    assert abs(float(o.loss) - float(oe.loss)) < 1e-4 * abs(float(oe.loss))
+    assert (o2.logits.float() - oe.logits[:, 16:-1].float()).abs().max() < 1e-4
+    lm.train()
+    o3 = lm(**kw, return_logits=True)
+    assert o3.logits.shape == (2, 24, 128)
