@@ -169,12 +169,13 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
 
     f32x4 acc[4][8];
 
-#define P8_MM(FX, FW, J0, T0)                                                                  \
+    // the 16 MFMAs of a phase, MFMAs [I0, I1) of the order (ks, j, t)
+#define P8_MM(FX, FW, J0, T0, I0, I1)                                                          \
     do {                                                                                       \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                    \
-            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                   \
-                _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                               \
-                    mma16(acc[(T0) + t_][(J0) + j_], FW[ks_][t_], FX[ks_][j_]);                \
+        _Pragma("unroll") for (int i_ = (I0); i_ < (I1); ++i_) {                               \
+            const int ks_ = i_ >> 3, j_ = (i_ >> 1) & 3, t_ = i_ & 1;                          \
+            mma16(acc[(T0) + t_][(J0) + j_], FW[ks_][t_], FX[ks_][j_]);                        \
+        }                                                                                      \
     } while (0)
 
     int m0 = 0, n0 = 0, m1 = 0, n1 = 0;
@@ -286,7 +287,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     // K tile kt + DK (past the end of this output tile: K tile kt + DK - nk of the next one).  vmcnt(10): the 5 younger units
     // may stay in flight.  MMA: the 16 MFMAs.  The memory cluster is the critical path of the ping-pong (two LDS-DMA issues and
     // up to 8 ds_reads against the partner's 16 MFMAs): nothing else lives in this loop -- no branch, no address arithmetic.
-#define P8_PHASE(READ, TY, SLOT, DK, MMA)                                                        \
+#define P8_PHASE(READ, TY, SLOT, DK, FX, FW, J0, T0)                                             \
     do {                                                                                         \
         READ;                                                                                    \
         {                                                                                        \
@@ -301,10 +302,15 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         P8_LGKM_PHASE();                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         __builtin_amdgcn_s_setprio(1);                                                           \
-        MMA;                                                                                     \
-        __builtin_amdgcn_s_setprio(0);                                                           \
+        /* the barrier that hands the matrix pipe to the partner wave sits BEFORE this wave's last MFMA: the partner's first      */ \
+        /* MFMAs queue behind it instead of behind a drained pipe (+1-2 %; two or more MFMAs after the barrier lose 7 %)          */ \
+        P8_MM(FX, FW, J0, T0, 0, 15);                                                            \
+        P8_LGKM0();                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         P8_BARRIER();                                                                            \
+        P8_MM(FX, FW, J0, T0, 15, 16);                                                           \
+        __builtin_amdgcn_s_setprio(0);                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
     } while (0)
 
     for (;;) {
@@ -312,14 +318,14 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         // is a counted vmcnt behind many younger loads, never a drain of the LDS-DMA stream)
         fetch_bias(n0);
         for (int kt = 0; kt < nk; kt += 2) {
-            P8_PHASE(rdX(fx, 0), 2, 6, 1, P8_MM(fx, fwA, 0, 0));
-            P8_PHASE(rdW(fwB, 1), 3, 7, 2, P8_MM(fx, fwB, 0, 2));
-            P8_PHASE(rdX(fx, 2), 0, 0, 2, P8_MM(fx, fwB, 4, 2));
-            P8_PHASE(rdW(fwB, 3), 1, 1, 2, P8_MM(fx, fwA, 4, 0));
-            P8_PHASE(rdX(fx, 4), 2, 2, 2, P8_MM(fx, fwB, 0, 0));
-            P8_PHASE(rdW(fwA, 5), 3, 3, 3, P8_MM(fx, fwA, 0, 2));
-            P8_PHASE(rdX(fx, 6), 0, 4, 3, P8_MM(fx, fwA, 4, 2));
-            P8_PHASE(rdW(fwA, 7), 1, 5, 3, P8_MM(fx, fwB, 4, 0));
+            P8_PHASE(rdX(fx, 0), 2, 6, 1, fx, fwA, 0, 0);
+            P8_PHASE(rdW(fwB, 1), 3, 7, 2, fx, fwB, 0, 2);
+            P8_PHASE(rdX(fx, 2), 0, 0, 2, fx, fwB, 4, 2);
+            P8_PHASE(rdW(fwB, 3), 1, 1, 2, fx, fwA, 4, 0);
+            P8_PHASE(rdX(fx, 4), 2, 2, 2, fx, fwB, 0, 0);
+            P8_PHASE(rdW(fwA, 5), 3, 3, 3, fx, fwA, 0, 2);
+            P8_PHASE(rdX(fx, 6), 0, 4, 3, fx, fwA, 4, 2);
+            P8_PHASE(rdW(fwA, 7), 1, 5, 3, fx, fwB, 4, 0);
         }
         // epilogue of tile (m0, n0), beside the partner wave's MFMAs (waves 0-3 and 4-7 reach it half a phase apart)
         prefetch_zr();
