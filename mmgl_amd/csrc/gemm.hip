@@ -791,7 +791,9 @@ inline int tt256_splits(int RA, int RB, int K) {
     return 0;
 }
 inline size_t tt256_partial_bytes(int RA, int RB, int K) {
-    const int s = tt256_splits(RA, RB, K);
+    int s = tt256_splits(RA, RB, K);
+    const int s8 = gemm8p_tt_splits(RA, RB, K);
+    if (s8 > s) s = s8;
     return s > 1 ? align_up((size_t)s * RA * RB * sizeof(float), 256) : 0;
 }
 
@@ -864,6 +866,19 @@ int launch_gemm_tx(bool tb, const bf16* Aop, int lda, const bf16* Bop, int ldb, 
                    int K, float scale, int accumulate, hipStream_t st, float* part = nullptr) {
     MMGL_CHECK_ARG(RA > 0 && RB > 0 && K > 0, "gemm_tx: bad sizes");
     if (RA % 8 || (tb ? RB % 8 : K % 8)) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm_tx: feature dims must be multiples of 8");
+    if (tb && !ymask && tune_gemm_8p()) {
+        // both operands k-major and enough (tile, K split) work items: the ping-pong weight-gradient kernel (gemm8p_tt.hip)
+        const int s8 = gemm8p_tt_splits(RA, RB, K);
+        if (s8 == 1 || (s8 > 1 && part)) {
+            int rc = launch_gemm8p_tt(Aop, lda, Bop, ldb, Out, part, RA, RB, K, s8, scale, accumulate, st);
+            if (rc || s8 == 1) return rc;
+            const size_t n4 = (size_t)RA * RB / 4;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256)), dim3(256), 0, st, part,
+                               Out, n4, s8, scale, accumulate);
+            MMGL_CHECK_LAUNCH("splitk_reduce");
+            return MMGL_OK;
+        }
+    }
     const int nsplit = (tb && !ymask && tune_gemm_big()) ? tt256_splits(RA, RB, K) : 0;
     if (nsplit == 1 || (nsplit > 1 && part)) {
         // both operands k-major and a full chip of 256x256 tiles (with K splits for small outputs): the big-tile kernel

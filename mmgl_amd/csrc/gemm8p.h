@@ -7,3 +7,8 @@
 bool gemm8p_supported(int M, int N, int K, int ldx, int ldw, int ldy);
 int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, const bf16* resid,
                   const bf16* zmask, int M, int N, int K, int act, float scale, hipStream_t st);
+
+// weight gradient on the same structure (gemm8p_tt.hip): Out[RB][RA] = scale * sum_m B[m][rb] A[m][ra], both operands k-major
+int gemm8p_tt_splits(int RA, int RB, int M);
+int launch_gemm8p_tt(const bf16* A, int lda, const bf16* B, int ldb, bf16* Out, float* part, int RA, int RB, int M, int nsplit, float scale,
+                     int accumulate, hipStream_t st);
