@@ -234,15 +234,19 @@ __global__ __launch_bounds__(512) void gemm8p_tt_kernel(T8Args a) {
 
 }  // namespace
 
-// number of K splits (0 = shape not eligible): enough work items to fill the chip, whole K-tile pairs per split
+// number of K splits (0 = shape not eligible): enough (tile, split) work items to fill the chip, whole K-tile pairs per split.
+// Few-tile outputs (a 2048 x 2048 weight: 64 tiles; a rank-padded LoRA factor: 8) take up to 16 splits and run with as few as
+// 64 work items -- still far ahead of the non-persistent 128 x 128 kernel, which has no K split at all.
 int gemm8p_tt_splits(int RA, int RB, int M) {
     if (RA % 256 || RB % 256 || M % 128) return 0;
     const int tiles = (RA / 256) * (RB / 256);
+    int best = 0;
     for (int s = 1; s <= 16; s *= 2) {
         if (M % (128 * s) || M / s < 256) break;
+        best = s;
         if (tiles * s >= 192) return s;
     }
-    return 0;
+    return (best && tiles * best >= 64) ? best : 0;
 }
 
 int launch_gemm8p_tt(const bf16* A, int lda, const bf16* B, int ldb, bf16* Out, float* part, int RA, int RB, int M, int nsplit, float scale,

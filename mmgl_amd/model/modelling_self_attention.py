@@ -158,6 +158,8 @@ class SelfAttentionModel(nn.Module):
             self.visual_model.eval()
             for p in self.visual_model.parameters():
                 p.requires_grad = False
+            from .modelling_cross_attention import _conv_patch_embed_as_gemm
+            _conv_patch_embed_as_gemm(self.visual_model)     # CLIP's stride == kernel patch Conv2d as a GEMM (MIOpen falls back to naive_conv)
 
         if self.position_type == "laplacian":
             if self.context in ("section_only", "section_all", "text_only") or self.neighbor_mode == "raw":

@@ -465,8 +465,14 @@ def lora_linear(x, weight, bias, lora_A, lora_B, scale):
     N, K = weight.shape
     if (not weight.requires_grad and (bias is None or not bias.requires_grad) and x.is_cuda
             and lib().mmgl_gemm_nt_fast(M, N, K, K, K, N, dtype_code(x))):
-        xa = linear(x, lora_A)                                     # [.., r]
-        delta = linear(xa, lora_B, out_scale=scale)                # [.., N]
+        # the rank is zero-padded to 256 (autograd slices the gradients back): every product of the low-rank path -- x A^T,
+        # (x A^T) B^T, and in backward dy B, (dy B) A, (dy B)^T x, dy^T (x A^T) -- is then a 256-wide GEMM the large-tile kernels
+        # (and their K splits) carry, instead of a 16-wide one on a handful of workgroups
+        rp = (-lora_A.shape[0]) % 256
+        A_pad = F.pad(lora_A, (0, 0, 0, rp)) if rp else lora_A
+        B_pad = F.pad(lora_B, (0, rp)) if rp else lora_B
+        xa = linear(x, A_pad)                                      # [.., 256]
+        delta = linear(xa, B_pad, out_scale=scale)                 # [.., N]
         return frozen_linear(x, weight, bias, residual=delta)
     return _LoraLinear.apply(x, weight, bias, lora_A, lora_B, float(scale))
 
