@@ -185,18 +185,19 @@ def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1, repeats=3):
 
 def pmc_traffic(B, lm_cfg, cfg, dtype):
     """HBM bytes per launch of xattn_fwd_kernel from the committed PMC collection (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate passes, gfx950 x2 fetch correction applied: profiles/r1_pmc_xattn_*.json) when it was taken at this exact
+    separate passes, gfx950 x2 fetch correction applied: profiles/r<round>_pmc_xattn_*.json) when it was taken at this exact
     shape; None otherwise -- PMC counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, "profiles", f"r1_pmc_xattn_B{B}_{dtype}.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        c = d["config"]
-        if (c["B"], c["H"], c["S"], c["D"]) == (B, lm_cfg.num_attention_heads, (cfg["nt"] + cfg["ni"]) * 4,
-                                               lm_cfg.hidden_size // lm_cfg.num_attention_heads) and c["T"] == 640:
-            return d["kernels"]["xattn_fwd_kernel"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    for rnd in ("r2", "r1"):                                 # the latest round's collection first
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_xattn_B{B}_{dtype}.json")
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            c = d["config"]
+            if (c["B"], c["H"], c["S"], c["D"]) == (B, lm_cfg.num_attention_heads, (cfg["nt"] + cfg["ni"]) * 4,
+                                                   lm_cfg.hidden_size // lm_cfg.num_attention_heads) and c["T"] == 640:
+                return d["kernels"]["xattn_fwd_kernel"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
     return None
 
 

@@ -704,6 +704,254 @@ __global__ __launch_bounds__(64) void xattn_bwd_dkv64_kernel(const bf16* __restr
     }
 }
 
+// ============================================================================================ backward, fused (bf16, D <= 64, S <= 64)
+// dQ, dK and dV out of ONE pass over Q and dO: a wave owns (batch, head, T-chunk) and ALL keys, streams 32-row tiles
+// (requested one tile ahead, bounds by buffer descriptors) and per tile
+//   1. swapped products S^T = K Q^T, dP^T = V dO^T (lane = query row): P from the saved LSE, delta = sum_s P dP in-lane,
+//      dS = P (dP - delta), dQ^T = K^T dS^T with dS^T straight out of the accumulators (as xattn_bwd_dq_kernel);
+//   2. P and dS (bf16) dropped row-major into a wave-private LDS tile next to the tile's Q and dO rows, and read back with
+//      ds_read_b64_tr_b16 as the operands of the contraction over t:  dV^T[d][s] += dO^T[d][t] P[t][s],
+//      dK^T[d][s] += Q^T[d][t] dS[t][s]  (accumulators live in registers for the whole chunk).
+// HBM traffic = the algorithmic minimum: Q and dO read once, dQ written once, no delta array, no second pass over Q / dO
+// (the two-kernel path reads them twice), and with one chunk per (batch, head) dK / dV are written once in bf16 with no
+// fp32 partials.  One wave per workgroup: no barrier anywhere, every dK / dV element of a chunk is produced by one wave.
+template <int D, int NSB>
+__global__ __launch_bounds__(64) void xattn_bwd_fused_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ q,
+                                                             const bf16* __restrict__ k, const bf16* __restrict__ v,
+                                                             const float* __restrict__ lse, const uint8_t* __restrict__ valid,
+                                                             bf16* __restrict__ dq, bf16* __restrict__ dk, bf16* __restrict__ dv,
+                                                             float* __restrict__ dk_part, float* __restrict__ dv_part, int B, int H,
+                                                             int T_, int S, int rows_per_chunk, int nchunk) {
+    typedef bf16 T;
+    typedef XC<T, D, NSB, 2> C;
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    static_assert(C::QT == 2, "fused backward: a tile is one 32-row contraction step");
+    constexpr int LDT = C::DPAD + 16;              // Q / dO tile row stride (elements)
+    constexpr int LDP = C::SPAD + 16;              // P / dS tile row stride
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ki = (T*)smem;                              // row-major padded: row fragments (S^T) and tr16 fragments (K^T)
+    T* Vf = Ki + C::RMIMG;                         // fragment-linear row image
+    T* Qt = Vf + C::ROWIMG;                        // [32][LDT]
+    T* Gt = Qt + 32 * LDT;
+    T* Pt = Gt + 32 * LDT;                         // [32][LDP]
+    T* DSt = Pt + 32 * LDP;
+    uint8_t* vld = (uint8_t*)(DSt + 32 * LDP);
+
+    const int lane = threadIdx.x, x = lane & 15, g = lane >> 4;
+    const int vid = xcd_remap(blockIdx.x, B * H * nchunk);
+    const int bh = vid / nchunk, chunk = vid % nchunk;
+    const int b = bh / H, h = bh % H;
+    const size_t HD = (size_t)H * D;
+    const int row_begin = chunk * rows_per_chunk, row_end = min(row_begin + rows_per_chunk, T_);
+
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t slab = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(dout + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dq + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
+
+    // two tiles in flight: a register set is re-requested (two tiles ahead) as soon as its swapped products are issued
+    v8 qA[2][C::NDC], gA[2][C::NDC], qB[2][C::NDC], gB[2][C::NDC];
+    float lA[2], lB[2];
+    auto request = [&](int tbase, v8 (&qn)[2][C::NDC], v8 (&gn)[2][C::NDC], float (&lsn)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int t = (tbase < row_end) ? tbase + qt * 16 + x : T_;      // past the chunk: every access falls outside the slab
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc) {
+                qn[qt][dc] = buf_load8<T>(rq, row_off<T, C>(t, row_bytes, dc * 32 + g * 8));
+                gn[qt][dc] = buf_load8<T>(rg, row_off<T, C>(t, row_bytes, dc * 32 + g * 8));
+            }
+            lsn[qt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (uint32_t)t * 4u, 0, 0));
+        }
+    };
+    request(row_begin, qA, gA, lA);
+    request(row_begin + 32, qB, gB, lB);
+
+    stage_rowmajor_image<T, C>(Ki, k + (size_t)b * S * HD + h * D, HD, S);
+    stage_row_image<T, C>(Vf, v + (size_t)b * S * HD + h * D, HD, S);
+    for (int i = lane; i < C::SPAD; i += 64) vld[i] = (i < S) ? valid[(size_t)b * S + i] : 0;
+    __syncthreads();
+
+    uint32_t vlo, vhi, elo, ehi;
+    lane_key_bits<C>(vld, g, S, vlo, vhi, elo, ehi);
+    const bool any_valid = __ballot((vlo | vhi) != 0) != 0ull;
+    const float uni = 1.f / (float)S;
+    const float tie = any_valid ? 1.f : 0.5f;                 // autograd's 50/50 split at the torch.max tie
+    f32x4 bias[C::NSB];
+    key_bias<C>(vlo, vhi, bias);
+
+    f32x4 dva[C::NDB][C::NSB], dka[C::NDB][C::NSB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int sb = 0; sb < C::NSB; ++sb) { dva[db][sb] = vzero<f32x4>(); dka[db][sb] = vzero<f32x4>(); }
+
+    v4 ost[2][C::NDB];
+    int tprev = T_;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) ost[qt][db] = vzero<v4>();
+    auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) store_row_tiles<T, C>(rd, tprev + qt * 16 + x, T_, row_bytes, g, ost[qt]);
+    };
+
+    auto step = [&](int t0, v8 (&qf)[2][C::NDC], v8 (&gf)[2][C::NDC], float (&lsn)[2]) __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");                        // the K / V fragments are re-read from LDS every tile (no hoisting: registers)
+        float l2[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) l2[qt] = (t0 + qt * 16 + x < row_end) ? lsn[qt] * LOG2E : INFINITY;     // row past the chunk: p = 0
+        flush();                                              // VMEM order per wave: stores(i-1), compute(i) ... loads(i+2)
+        tprev = t0;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc) {
+                *(v8*)(Qt + (qt * 16 + x) * LDT + dc * 32 + g * 8) = qf[qt][dc];
+                *(v8*)(Gt + (qt * 16 + x) * LDT + dc * 32 + g * 8) = gf[qt][dc];
+            }
+
+        v8 dsf[2][C::NKS];
+        {
+            f32x4 sacc[2][C::NSB], pacc[2][C::NSB];
+#pragma unroll
+            for (int sb = 0; sb < C::NSB; ++sb) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) { sacc[qt][sb] = bias[sb]; pacc[qt][sb] = vzero<f32x4>(); }
+#pragma unroll
+                for (int dc = 0; dc < C::NDC; ++dc) {
+                    const v8 kf = rm_rowfrag<T, C>(Ki, sb, dc, lane);
+                    const v8 vf = *(const v8*)(Vf + rf_idx<C>(sb, dc, lane));
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        mma16(sacc[qt][sb], kf, qf[qt][dc]);
+                        mma16(pacc[qt][sb], vf, gf[qt][dc]);
+                    }
+                }
+            }
+            request(t0 + 64, qf, gf, lsn);                    // this set's rows are consumed (LDS tile + MFMA operands): next-but-one tile
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const bool live = t0 + qt * 16 + x < row_end;
+                float dl = 0.f;
+#pragma unroll
+                for (int sb = 0; sb < C::NSB; ++sb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p;
+                        if (any_valid) p = __builtin_amdgcn_exp2f(fmaf(sacc[qt][sb][r], LOG2E, -l2[qt]));    // masked key: exp2(-inf) = 0
+                        else p = (live && bit64(elo, ehi, sb * 4 + r)) ? uni : 0.f;
+                        sacc[qt][sb][r] = p;
+                        dl += p * pacc[qt][sb][r];
+                    }
+                    *(v4*)(Pt + (qt * 16 + x) * LDP + sb * 16 + g * 4) = cvt4<T>(sacc[qt][sb]);
+                }
+                dl = xg_sum(dl);
+                v4 dsb[C::NSB];
+#pragma unroll
+                for (int sb = 0; sb < C::NSB; ++sb) {
+                    f32x4 d4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d4[r] = tie * sacc[qt][sb][r] * (pacc[qt][sb][r] - dl);
+                    dsb[sb] = cvt4<T>(d4);
+                    *(v4*)(DSt + (qt * 16 + x) * LDP + sb * 16 + g * 4) = dsb[sb];
+                }
+#pragma unroll
+                for (int ks = 0; ks < C::NKS; ++ks) {
+                    const v4 lo = dsb[2 * ks], hi = dsb[2 * ks + 1];
+                    dsf[qt][ks] = v8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            }
+        }
+        {
+            f32x4 acc[2][C::NDB];
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) acc[qt][db] = vzero<f32x4>();
+#pragma unroll
+                for (int ks = 0; ks < C::NKS; ++ks) {
+                    const v8 kt = rm_tfrag_tr16<C>(Ki, db, ks, lane);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) mma16(acc[qt][db], kt, dsf[qt][ks]);
+                }
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) ost[qt][db] = cvt4<T>(acc[qt][db]);
+        }
+        // contraction over the tile's 32 rows; LDS ops of one wave execute in order, the fences only stop compiler reordering
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+            const int trow = 4 * g + (x >> 2), tcol = (x & 3) * 4;
+            v8 pB[C::NSB], dsB[C::NSB];
+#pragma unroll
+            for (int sb = 0; sb < C::NSB; ++sb) {
+                const bf16* pp = Pt + trow * LDP + sb * 16 + tcol;
+                const bf16* pd = DSt + trow * LDP + sb * 16 + tcol;
+                const bf16x4 p0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pp);
+                const bf16x4 p1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pp + 16 * LDP));
+                const bf16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pd);
+                const bf16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pd + 16 * LDP));
+                pB[sb] = v8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+                dsB[sb] = v8{d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+            }
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db) {
+                const bf16* pg = Gt + trow * LDT + db * 16 + tcol;
+                const bf16* pq = Qt + trow * LDT + db * 16 + tcol;
+                const bf16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pg);
+                const bf16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pg + 16 * LDT));
+                const bf16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pq);
+                const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pq + 16 * LDT));
+                const v8 gT = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                const v8 qT = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+                for (int sb = 0; sb < C::NSB; ++sb) {
+                    mma16(dva[db][sb], gT, pB[sb]);
+                    mma16(dka[db][sb], qT, dsB[sb]);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int t0 = row_begin; t0 < row_end; t0 += 64) {
+        step(t0, qA, gA, lA);
+        if (t0 + 32 < row_end) step(t0 + 32, qB, gB, lB);
+    }
+    flush();                                                  // the last tile's dQ
+
+#pragma unroll
+    for (int sb = 0; sb < C::NSB; ++sb) {
+        const int s = sb * 16 + x;
+        if (s < S) {
+            if (nchunk == 1) {
+                const size_t off = ((size_t)b * S + s) * HD + h * D + g * 4;
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) {
+                    store4<T>(dk + off + db * 16, dka[db][sb]);
+                    store4<T>(dv + off + db * 16, dva[db][sb]);
+                }
+            } else {
+                const size_t off = (((size_t)chunk * B + b) * S + s) * HD + h * D + g * 4;
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) {
+                    *(f32x4*)(dk_part + off + db * 16) = dka[db][sb];
+                    *(f32x4*)(dv_part + off + db * 16) = dva[db][sb];
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, T* __restrict__ outp,
                                                               size_t n4, size_t chunk_stride4, int nchunk) {
@@ -723,6 +971,10 @@ inline bool use_dkv64(int D, size_t esz) {
     return on && esz == 2;
 }
 inline int dkv64_keys(int D) { return D <= 64 ? 64 : 32; }
+inline bool use_fused_bwd() {
+    static const int on = [] { const char* e = getenv("MMGL_XATTN_FUSED_BWD"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
 
 BwdPlan bwd_plan(int B, int H, int T, int S, int D, size_t esz = 2) {
     BwdPlan p;
@@ -794,6 +1046,28 @@ int launch_bwd(const void* dout, const void* q, const void* k, const void* v, co
     float* delta = (float*)(ws + p.delta_off);
     float* dkp = (float*)(ws + p.dk_off);
     float* dvp = (float*)(ws + p.dv_off);
+    if constexpr (sizeof(T) == 2 && D <= 64 && NSB <= 4) {
+        if (use_fused_bwd()) {                                // one pass over Q / dO (p.nsg == 1 here: all keys in one wave)
+            constexpr int LDT = C::DPAD + 16, LDP = C::SPAD + 16;
+            const size_t lds = sizeof(bf16) * (C::RMIMG + C::ROWIMG + 2 * 32 * LDT + 2 * 32 * LDP) + C::SPAD;
+            auto kern = xattn_bwd_fused_kernel<D, NSB>;
+            int rc = set_lds(kern, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(kern, dim3(B * H * p.nchunk), dim3(64), lds, st, (const bf16*)dout, (const bf16*)q, (const bf16*)k,
+                               (const bf16*)v, lse, valid, (bf16*)dq, (bf16*)dk, (bf16*)dv, dkp, dvp, B, H, T_, S, p.rows_per_chunk,
+                               p.nchunk);
+            MMGL_CHECK_LAUNCH("xattn_bwd_fused");
+            if (p.nchunk > 1) {
+                size_t n4 = (size_t)B * S * H * D / 4;
+                int blocks = (int)((n4 + 255) / 256);
+                if (blocks > 2048) blocks = 2048;
+                hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3(blocks), dim3(256), 0, st, dkp, (T*)dk, n4, n4, p.nchunk);
+                hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3(blocks), dim3(256), 0, st, dvp, (T*)dv, n4, n4, p.nchunk);
+                MMGL_CHECK_LAUNCH("xattn_bwd_reduce");
+            }
+            return MMGL_OK;
+        }
+    }
     {
         int rpw, nchunk;
         fwd_geometry(B, H, T_, 16 * C::QT, rpw, nchunk);

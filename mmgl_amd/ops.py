@@ -227,6 +227,7 @@ class _AddLayerNorm(torch.autograd.Function):
         _lib.call("mmgl_add_layernorm_fwd", dict(bytes=4.0 * rows * cols * x.element_size()), ptr(x2), ptr(r2), ptr(g), ptr(b), ptr(s), ptr(y),
                   ptr(mean), ptr(rstd), rows, cols, eps, p_drop, seed, dtype_code(x), stream_ptr())
         ctx.save_for_backward(s, g, mean, rstd)
+        ctx.set_materialize_grads(False)                      # an unused output arrives as None, not as a zero tensor to stream
         ctx.shape, ctx.p, ctx.seed = shape, p_drop, seed
         ctx.pgrad = (gamma is not None and gamma.requires_grad, beta is not None and beta.requires_grad)
         ctx.pdtype = None if gamma is None else gamma.dtype
@@ -238,6 +239,8 @@ class _AddLayerNorm(torch.autograd.Function):
         rows, cols = s.shape
         p = ctx.p
         if dy is None:                                        # only the residual stream was used downstream
+            if ds is None:
+                return None, None, None, None, None, None, None
             if p == 0.0:
                 return ds, ds, None, None, None, None, None
             dy = torch.zeros_like(ds)
