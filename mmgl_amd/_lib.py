@@ -9,7 +9,7 @@ import os
 import torch  # imported first on purpose: the .so must bind to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmgl_hip.so")
+LIB_PATH = os.environ.get("MMGL_LIB_PATH") or os.path.join(_HERE, "libmmgl_hip.so")     # override: timing experiments with ablated builds
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
@@ -128,6 +128,7 @@ class KernelTimer:
     enabled = False
     only = None           # optional set of entry-point names: time just these (bench.py's timed region: the roofline kernel)
     records = []          # (name, start_event, end_event, work dict)
+    by_tag = bool(os.environ.get("MMGL_KERNEL_TAGS"))     # split the table by the calls' `tag` (GEMM shapes) as well
 
     @classmethod
     def reset(cls):
@@ -139,6 +140,8 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for name, s, e, work in cls.records:
+            if cls.by_tag and "tag" in work:
+                name = f"{name}[{work['tag']}]"
             d = out.setdefault(name, dict(calls=0, ms_total=0.0, bytes=0.0, flops=0.0))
             d["calls"] += 1
             d["ms_total"] += s.elapsed_time(e)

@@ -5,8 +5,10 @@
 //
 // Structure (one workgroup = 8 waves = one CU, persistent over output tiles):
 //   * wave (wr, wc) = (wave >> 2, wave & 3) owns a 128 (m) x 64 (n) block of the 256x256 tile: 128 fp32 accumulator VGPRs.
-//     W is the MFMA A operand with its 16 fragment rows mapped to n = 16 g' + 4 t + r  (a free row permutation in the
-//     fragment addressing), so a lane ends up with 16 CONSECUTIVE output columns of one output row: 2 x 16-byte stores,
+//     W is the MFMA A operand with its fragment rows mapped to n = 32 (t >> 1) + 8 g' + 4 (t & 1) + r  (a free row
+//     permutation in the staging addresses), so a lane ends up with 8 CONSECUTIVE output columns per fragment-row pair and the
+//     four lanes of an output row with 64 contiguous bytes: one 16-byte store per lane, whole 64-byte segments per instruction
+//     (the first mapping, 16 g' + 4 t + r, wrote 16-byte pieces at a 32-byte pitch: ~9 us of store drain per tile),
 //     bias / activation / residual without cross-lane traffic.
 //   * the two waves that share a SIMD (w and w + 4) run half a phase apart: a phase is  [ds_read fragments | issue LDS-DMA |
 //     s_waitcnt vmcnt(N)] s_barrier [16 MFMA] s_barrier ; waves 4-7 take one extra barrier up front, so while one wave of
@@ -27,6 +29,7 @@
 #include "common.h"
 #include "gemm8p.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -35,6 +38,7 @@ typedef unsigned p8_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int P8_UNIT = 16384;      // bytes per staged unit
 constexpr int P8_LDS = 8 * P8_UNIT;
+constexpr int P8_LDS_TOTAL = P8_LDS + 8 * 1024;      // + one 1 KiB bias line per wave
 
 struct P8Args {
     const bf16* X;
@@ -48,11 +52,12 @@ struct P8Args {
     float scale;
     int act;
     int tiles_m, tiles_n, total;
+    int stagger;           // start delay per CU group in units of 4096 clocks (0 = none)
+    long long* trace;      // timing experiments only (P8_TRACE builds): [8 waves][64] clock stamps of workgroup 0
 };
 
-// ACT is a compile-time family: 0 = none / ReLU (a clamp against `lo` = 0 or -inf, branch-free), 2 gelu (erf), 3 quick_gelu,
-// 4 gelu (tanh)
-template <int ACT> __device__ __forceinline__ float p8_act(float v, float lo) {
+// ACT is a compile-time family: 0 = none, 1 = ReLU, 2 gelu (erf), 3 quick_gelu, 4 gelu (tanh)
+template <int ACT> __device__ __forceinline__ float p8_act(float v) {
     if constexpr (ACT == 2) {
         // exact-GELU with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): ~14 VALU per value instead
         // of libm's erff -- the epilogue runs beside the partner wave's MFMAs and must stay short
@@ -66,7 +71,8 @@ template <int ACT> __device__ __forceinline__ float p8_act(float v, float lo) {
     else if constexpr (ACT == 4) {
         const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
         return 0.5f * v * (1.f + tanhf(u));
-    } else return fmaxf(v, lo);
+    } else if constexpr (ACT == 1) return fmaxf(v, 0.f);
+    else return v;
 }
 
 // lane id from the exec mask (v_mbcnt): recomputed where it is needed instead of keeping a register (or, under this kernel's
@@ -78,6 +84,18 @@ __device__ __forceinline__ int p8_lane() {
     return l;
 }
 
+#ifndef P8_RELAX
+#define P8_RELAX 0                   // 1: relaxed vmcnt in a tile's first five phases (peeled first K-tile pair); measured neutral, kept for experiments
+#endif
+#ifndef P8_REALIGN
+#define P8_REALIGN 1                 // one extra barrier per wave group and tile: both groups' epilogues between the same two barriers
+#endif
+#ifndef P8_TRACE
+#define P8_TRACE 0                   // timing experiments only: clock stamps of workgroup 0 into P8Args::trace
+#endif
+#ifndef P8_ABLATE
+#define P8_ABLATE 0                  // timing experiments only (1: no epilogue, 2: epilogue without its stores); never set in a shipped build
+#endif
 #define P8_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define P8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define P8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -134,7 +152,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
             if (!(ty & 1)) srow = (lr >> 6) * 128 + (ty == 2 ? 64 : 0) + (lr & 63);
             else {
                 const int u = ty == 1 ? 1 : 0, tt = (lr >> 4) & 1, xp = lr & 15;
-                srow = (lr >> 5) * 64 + 16 * (xp >> 2) + 4 * (2 * u + tt) + (xp & 3);
+                srow = (lr >> 5) * 64 + 32 * u + 8 * (xp >> 2) + 4 * tt + (xp & 3);      // n = 32 (t >> 1) + 8 g + 4 (t & 1) + r
             }
             voff[ty][i] = srow * ((ty & 1) ? a.ldw : a.ldx) * 2 + c * 16;
         }
@@ -168,6 +186,19 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     };
 
     f32x4 acc[4][8];
+#if P8_TRACE
+    int tr_n = 0;
+    auto stamp = [&](int it_) __attribute__((always_inline)) {
+        if (a.trace && blockIdx.x == 0 && it_ >= 2 && tr_n < 64) {
+            const long long t = __builtin_readcyclecounter();
+            if (lane == 0) a.trace[wave * 64 + tr_n] = t;      // a plain store: perturbs vmcnt a little, same for every variant compared
+            ++tr_n;
+        }
+    };
+#define P8_STAMP(it_) stamp(it_)
+#else
+#define P8_STAMP(it_) (void)0
+#endif
 
     // the 16 MFMAs of a phase, MFMAs [I0, I1) of the order (ks, j, t)
 #define P8_MM(FX, FW, J0, T0, I0, I1)                                                          \
@@ -185,86 +216,133 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     __amdgpu_buffer_rsrc_t dXc = mk_desc(a.X, m0, a.M, a.ldx, true), dWc = mk_desc(a.W, n0, a.N, a.ldw, true);
     __amdgpu_buffer_rsrc_t dXn = mk_desc(a.X, m1, a.M, a.ldx, have_next), dWn = mk_desc(a.W, n1, a.N, a.ldw, have_next);
 
-    // ---- epilogue plumbing.  Lane (x, g) owns, for each of its 8 rows m = m0 + wr*128 + 16 J + x, the 16 columns
-    // n = n0 + wc*64 + 16 g + (4 t + r).  The lane's 16 bias values are fetched at the top of the tile's last K-tile pair, five
+    // ---- epilogue plumbing.  Lane (x, g) owns, for each of its 8 rows m = m0 + wr*128 + 16 J + x, the columns
+    // n = n0 + wc*64 + 32 (t >> 1) + 8 g + 4 (t & 1) + r.  The lane's 16 bias values are fetched at the top of the tile's last K-tile pair, five
     // phases before their first use, so that the wait for them is a counted vmcnt behind younger LDS-DMA loads, not a drain.
     // Output rows go through a buffer descriptor based at row m0 (rows past M and, via an all-ones offset, columns past N are
     // dropped by the hardware: no branches around the stores).
-    bf16x8 braw0, braw1;
-    // through a descriptor over bias[0..N) (empty without a bias): columns past N and the no-bias case read as zero, branch-free
+    // The wave's 64 bias values travel by LDS-DMA into a wave-private 1 KiB line past the unit ring (lanes 0-7 carry 16 bytes
+    // each, the others point outside the descriptor and deposit zeros): no register holds them across the tile.  The descriptor
+    // covers bias[0..N) (empty without a bias): columns past N and the no-bias case read as zero, branch-free.
     const __amdgpu_buffer_rsrc_t dBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 2 : 0, 0x00020000);
     auto fetch_bias = [&](int nt0) __attribute__((always_inline)) {
-        const int nb = nt0 + wc * 64 + 16 * (p8_lane() >> 4);
-        braw0 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dBias, nb * 2, 0, 0));
-        braw1 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dBias, nb * 2 + 16, 0, 0));
-    };
-    auto zero_acc = [&](int J0, int T0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[T0][J0 + j] = vzero<f32x4>(); acc[T0 + 1][J0 + j] = vzero<f32x4>(); }
+        const int ln = p8_lane();
+        const unsigned off = ln < 8 ? (unsigned)((nt0 + wc * 64 + ln * 8) * 2) : 0xffffffffu;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dBias, (lds_void*)(smem + P8_LDS + wave * 1024), 16, off, 0, 0, 0);
     };
     auto y_desc = [&](const bf16* base, int mt0) {
         long long rem = (long long)(a.M - mt0) * a.ldy * 2;
         if (rem > 0xffffffffLL) rem = 0xffffffffLL;
         return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)mt0 * a.ldy), 0, (int)(unsigned)rem, 0x00020000);
     };
-    const float relu_lo = a.act == 1 ? 0.f : -3.0e38f;
-    // epilogue of one quadrant (rows J0..J0+3 x fragment rows T0, T0+1 = 8 consecutive columns per lane): 4 x 16-byte stores
-    // per-lane byte offset of (row J, fragment-row half T0) inside the [M, ldy] output / zmask / residual
-    auto y_off = [&](int J, int T0) __attribute__((always_inline)) -> unsigned {
+    const bool has_bias = a.bias != nullptr, has_scale = a.scale != 1.f;       // wave-uniform: whole loops are skipped
+    // Epilogue of a tile.  Lane geometry is recomputed here (it must not live across the main loop), the bias / scale passes
+    // are whole-quadrant loops of packed fp32 ops behind uniform branches, and plain ReLU is one packed integer max on the
+    // converted bf16 pairs (a negative bf16 is a negative int16).  ZR kernels request the 16 zmask (else residual) vectors of
+    // the tile up front: one exposed memory latency per tile instead of one per quadrant.
+    auto epilogue = [&]() __attribute__((always_inline)) {
         const int ln = p8_lane();
-        const int ncol_l = wc * 64 + 16 * (ln >> 4);         // column of this lane inside the tile
-        return n0 + ncol_l < a.N ? (unsigned)((((wr * 128 + (ln & 15)) + J * 16) * a.ldy + n0 + ncol_l + 4 * T0) * 2) : 0xffffffffu;
-    };
-    // ZR kernels: the 16 zmask (else residual) vectors of the whole tile are requested up front, into the registers the
-    // K loop's fragments just vacated: one exposed memory latency per tile instead of one per quadrant
-    bf16x8 pre[16];
-    auto prefetch_zr = [&]() __attribute__((always_inline)) {
+        const int ncol_l = wc * 64 + 8 * (ln >> 4);          // first column of this lane inside the tile (fragment rows 0, 1)
+        const bool col_ok0 = n0 + ncol_l < a.N, col_ok1 = n0 + ncol_l + 32 < a.N;
+        const unsigned base = (unsigned)(((wr * 128 + (ln & 15)) * a.ldy + n0 + ncol_l) * 2);
+        const unsigned rstep = (unsigned)(16 * a.ldy * 2);
+        auto y_off = [&](int J, int T0) __attribute__((always_inline)) -> unsigned {
+            return (T0 ? col_ok1 : col_ok0) ? base + (unsigned)J * rstep + (unsigned)(32 * T0) : 0xffffffffu;
+        };
+        const __amdgpu_buffer_rsrc_t dY = y_desc(a.Y, m0);
+        bf16x8 pre[16];
         if constexpr (ZR) {
-            const bf16* src = a.zmask ? a.zmask : a.resid;
-            __amdgpu_buffer_rsrc_t dZ = y_desc(src, m0);
+            const __amdgpu_buffer_rsrc_t dZ = y_desc(a.zmask ? a.zmask : a.resid, m0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int J0 = (q == 0 || q == 1) ? 0 : 4, T0 = (q == 0 || q == 3) ? 0 : 2;       // order of the epi() calls below
+                    const int J0 = (q == 0 || q == 1) ? 0 : 4, T0 = (q == 0 || q == 3) ? 0 : 2;
                     pre[q * 4 + j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dZ, y_off(J0 + j, T0), 0, 0));
                 }
         }
-    };
-    auto epi = [&](int q, int J0, int T0) __attribute__((always_inline)) {
-        __amdgpu_buffer_rsrc_t dY = y_desc(a.Y, m0);
-        const bf16x8 br = T0 ? braw1 : braw0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned off = y_off(J0 + j, T0);
-            const f32x4 lo = acc[T0][J0 + j], hi = acc[T0 + 1][J0 + j];
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        for (int q = 0; q < 4; ++q) {
+            const int J0 = (q == 0 || q == 1) ? 0 : 4, T0 = (q == 0 || q == 3) ? 0 : 2;
+            if (has_bias) {
+                const bf16x8 br = *(const bf16x8*)(smem + P8_LDS + wave * 1024 + ((ln >> 4) + 2 * T0) * 16);     // columns 32 (T0 / 2) + 8 g ..
+                const f32x4 b0 = {(float)br[0], (float)br[1], (float)br[2], (float)br[3]}, b1 = {(float)br[4], (float)br[5], (float)br[6], (float)br[7]};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (v[e] + (float)br[e]) * a.scale;
+                for (int j = 0; j < 4; ++j) { acc[T0][J0 + j] += b0; acc[T0 + 1][J0 + j] += b1; }
+            }
+            if (has_scale) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = p8_act<ACT>(v[e], relu_lo);
-            if constexpr (ZR) {
-                const bf16x8 z = pre[q * 4 + j];
-                if (a.zmask) {
+                for (int j = 0; j < 4; ++j) { acc[T0][J0 + j] *= a.scale; acc[T0 + 1][J0 + j] *= a.scale; }
+            }
+            // MODE (wave-uniform, ZR kernels): 1 = zmask only (applied to the packed bf16 output), 2 = residual only, 3 = both
+            auto rows = [&](auto mode_tag) __attribute__((always_inline)) {
+                constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = ((float)z[e] > 0.f) ? v[e] : 0.f;
-                    if (a.resid) {
-                        __amdgpu_buffer_rsrc_t dR = y_desc(a.resid, m0);
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned off = y_off(J0 + j, T0);
+                    const f32x4 lo = acc[T0][J0 + j], hi = acc[T0 + 1][J0 + j];
+                    f32x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if constexpr (ACT >= 2 || (ACT == 1 && ZR)) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = p8_act<ACT>(v[e]);
+                    }
+                    if constexpr (MODE == 2) {
+                        const bf16x8 z = pre[q * 4 + j];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)z[e];
+                    }
+                    if constexpr (MODE == 3) {
+                        const bf16x8 z = pre[q * 4 + j];
+                        const __amdgpu_buffer_rsrc_t dR = y_desc(a.resid, m0);
                         const bf16x8 rr = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dR, off, 0, 0));
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
+                        for (int e = 0; e < 8; ++e) v[e] = (((float)z[e] > 0.f) ? v[e] : 0.f) + (float)rr[e];
                     }
-                } else {
+                    p8_u32x4 ob = __builtin_bit_cast(p8_u32x4, __builtin_convertvector(v, bf16x8));
+                    if constexpr (ACT == 1 && !ZR) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)z[e];
+                        for (int e = 0; e < 4; ++e) {
+                            unsigned w = ob[e];
+                            asm("v_pk_max_i16 %0, %1, 0" : "=v"(w) : "v"(w));     // ReLU on two bf16: a negative bf16 is a negative int16
+                            ob[e] = w;
+                        }
+                    }
+                    if constexpr (MODE == 1) {
+                        // zmask > 0 on the raw bf16 pairs: negatives -> 0, positives -> 1, then 0 - that = 0xffff / 0 per half
+                        const p8_u32x4 zz = __builtin_bit_cast(p8_u32x4, pre[q * 4 + j]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            unsigned m = zz[e];
+                            asm("v_pk_max_i16 %0, %1, 0\n\tv_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]\n\tv_pk_sub_u16 %0, 0, %0" : "=v"(m) : "v"(m));
+                            ob[e] &= m;
+                        }
+                    }
+#if P8_ABLATE & 2
+                    asm volatile("" :: "v"(ob));
+#else
+                    __builtin_amdgcn_raw_buffer_store_b128(ob, dY, off, 0, 0);
+#endif
                 }
-            }
-            f32x8 o8 = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-            const bf16x8 ob = __builtin_convertvector(o8, bf16x8);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, ob), dY, off, 0, 0);
+            };
+            if constexpr (!ZR) rows(std::integral_constant<int, 0>());
+            else if (a.zmask && a.resid) rows(std::integral_constant<int, 3>());
+            else if (a.zmask) rows(std::integral_constant<int, 1>());
+            else rows(std::integral_constant<int, 2>());
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[T0][J0 + j] = vzero<f32x4>(); acc[T0 + 1][J0 + j] = vzero<f32x4>(); }
         }
-        zero_acc(J0, T0);
     };
+
+    // ---- stagger.  Every CU runs equal tiles in lockstep, so all 256 of them would reach their epilogues together and push
+    // 32 MiB of output at the memory system at once; with one in-order vmcnt per wave the next tile's LDS-DMA waits sit behind
+    // those stores, and the whole chip stalls for the drain (measured: ~9 us per tile, 1332 -> 1617 TF at K = 2048 with the
+    // stores removed).  Four groups of CUs (per XCD) start a quarter of a tile apart instead: a quarter of the CUs store while
+    // the others compute, each burst drains at the full bandwidth, and the offsets persist because every tile takes the same
+    // time.  Costs 3/4 of one tile time once per launch: only worth it over several rounds of tiles.
+    if (a.stagger) {
+        const int grp = (blockIdx.x >> 3) & 3;
+        for (int i = 0; i < grp * a.stagger; ++i) __builtin_amdgcn_s_sleep(64);          // 64 x 64 clocks each
+    }
 
     // ---- prologue: units -1 .. 5 of the stream  (Wa(0) | Xa(0) Wb(0) Xb(0) Wa(1) | Xa(1) Wb(1))
     stage(3, 7, dWc, 0);
@@ -274,10 +352,18 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     stage(3, 3, dWc, 128);
     stage(0, 4, dXc, 128);
     stage(1, 5, dWc, 128);
-    zero_acc(0, 0); zero_acc(0, 2); zero_acc(4, 0); zero_acc(4, 2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = vzero<f32x4>();
     // two W fragment sets that swap roles every K tile: even K tiles keep Wa in fwA and Wb in fwB, odd ones Wa in fwB, Wb in fwA
     bf16x8 fx[2][4], fwA[2][2], fwB[2][2];
-    P8_VMCNT(10);                        // units -1 and 0 have landed
+    fetch_bias(n0);                      // the lane's 16 bias values of the first tile
+#if P8_RELAX
+    P8_VMCNT(0);                         // the whole prologue has landed: the relaxed counts of a tile's first phases assume that
+#else                                    // everything issued before the tile is complete, or older than the epilogue's stores
+    P8_VMCNT(11);                        // units -1 and 0 have landed
+#endif
     P8_BARRIER();
     rdW(fwA, 7);
     P8_LGKM0();
@@ -287,7 +373,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     // K tile kt + DK (past the end of this output tile: K tile kt + DK - nk of the next one).  vmcnt(10): the 5 younger units
     // may stay in flight.  MMA: the 16 MFMAs.  The memory cluster is the critical path of the ping-pong (two LDS-DMA issues and
     // up to 8 ds_reads against the partner's 16 MFMAs): nothing else lives in this loop -- no branch, no address arithmetic.
-#define P8_PHASE(READ, TY, SLOT, DK, FX, FW, J0, T0)                                             \
+#define P8_PHASE_M(READ, TY, SLOT, DK, FX, FW, J0, T0, MM, WAITN)                                \
     do {                                                                                         \
         READ;                                                                                    \
         {                                                                                        \
@@ -297,43 +383,92 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
             if ((TY) & 1) stage((TY), (SLOT), nx_ ? dWn : dWc, kb_);                             \
             else stage((TY), (SLOT), nx_ ? dXn : dXc, kb_);                                      \
         }                                                                                        \
-        P8_VMCNT(10);                                                                            \
+        P8_VMCNT(WAITN);                                                                         \
         P8_BARRIER();                                                                            \
         P8_LGKM_PHASE();                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         __builtin_amdgcn_s_setprio(1);                                                           \
         /* the barrier that hands the matrix pipe to the partner wave sits BEFORE this wave's last MFMA: the partner's first      */ \
         /* MFMAs queue behind it instead of behind a drained pipe (+1-2 %; two or more MFMAs after the barrier lose 7 %)          */ \
-        P8_MM(FX, FW, J0, T0, 0, 15);                                                            \
+        MM(FX, FW, J0, T0, 0, 15);                                                               \
         P8_LGKM0();                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         P8_BARRIER();                                                                            \
-        P8_MM(FX, FW, J0, T0, 15, 16);                                                           \
+        MM(FX, FW, J0, T0, 15, 16);                                                              \
         __builtin_amdgcn_s_setprio(0);                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     } while (0)
 
+#define P8_PHASE(READ, TY, SLOT, DK, FX, FW, J0, T0) P8_PHASE_M(READ, TY, SLOT, DK, FX, FW, J0, T0, P8_MM, 10)
+    // the first 5 phases of an output tile: the previous tile's 16 output stores and this tile's bias load sit in the (single,
+    // in-order) VMEM queue between the units still in flight and the ones issued now.  The unit a phase needs is OLDER than all
+    // of them, so the count that keeps "5 younger units in flight" grows by 17: with vmcnt(10) the first phase of every tile
+    // would wait for the stores to be acknowledged (a 128 KiB burst per CU: 3-10k clocks) instead of running under them.
+#define P8_PHASE_T(READ, TY, SLOT, DK, FX, FW, J0, T0) P8_PHASE_M(READ, TY, SLOT, DK, FX, FW, J0, T0, P8_MM, 27)
     for (;;) {
         // the lane's 16 bias values for this tile: fetched now, consumed by the epilogue a whole tile later (the wait for them
         // is a counted vmcnt behind many younger loads, never a drain of the LDS-DMA stream)
-        fetch_bias(n0);
-        for (int kt = 0; kt < nk; kt += 2) {
-            P8_PHASE(rdX(fx, 0), 2, 6, 1, fx, fwA, 0, 0);
-            P8_PHASE(rdW(fwB, 1), 3, 7, 2, fx, fwB, 0, 2);
-            P8_PHASE(rdX(fx, 2), 0, 0, 2, fx, fwB, 4, 2);
-            P8_PHASE(rdW(fwB, 3), 1, 1, 2, fx, fwA, 4, 0);
-            P8_PHASE(rdX(fx, 4), 2, 2, 2, fx, fwB, 0, 0);
+        P8_STAMP(it);
+#if P8_RELAX
+        {
+            const int kt = 0;
+            P8_PHASE_T(rdX(fx, 0), 2, 6, 1, fx, fwA, 0, 0);
+            P8_STAMP(it);
+            P8_PHASE_T(rdW(fwB, 1), 3, 7, 2, fx, fwB, 0, 2);
+            P8_STAMP(it);
+            P8_PHASE_T(rdX(fx, 2), 0, 0, 2, fx, fwB, 4, 2);
+            P8_STAMP(it);
+            P8_PHASE_T(rdW(fwB, 3), 1, 1, 2, fx, fwA, 4, 0);
+            P8_STAMP(it);
+            P8_PHASE_T(rdX(fx, 4), 2, 2, 2, fx, fwB, 0, 0);
+            P8_STAMP(it);
             P8_PHASE(rdW(fwA, 5), 3, 3, 3, fx, fwA, 0, 2);
+            P8_STAMP(it);
             P8_PHASE(rdX(fx, 6), 0, 4, 3, fx, fwA, 4, 2);
+            P8_STAMP(it);
             P8_PHASE(rdW(fwA, 7), 1, 5, 3, fx, fwB, 4, 0);
+            P8_STAMP(it);
         }
+        for (int kt = 2; kt < nk; kt += 2) {
+#else
+        for (int kt = 0; kt < nk; kt += 2) {
+#endif
+            P8_PHASE(rdX(fx, 0), 2, 6, 1, fx, fwA, 0, 0);
+            if (kt < 4) P8_STAMP(it);
+            P8_PHASE(rdW(fwB, 1), 3, 7, 2, fx, fwB, 0, 2);
+            if (kt < 4) P8_STAMP(it);
+            P8_PHASE(rdX(fx, 2), 0, 0, 2, fx, fwB, 4, 2);
+            if (kt < 4) P8_STAMP(it);
+            P8_PHASE(rdW(fwB, 3), 1, 1, 2, fx, fwA, 4, 0);
+            if (kt < 4) P8_STAMP(it);
+            P8_PHASE(rdX(fx, 4), 2, 2, 2, fx, fwB, 0, 0);
+            if (kt < 4) P8_STAMP(it);
+            P8_PHASE(rdW(fwA, 5), 3, 3, 3, fx, fwA, 0, 2);
+            if (kt < 4) P8_STAMP(it);
+            P8_PHASE(rdX(fx, 6), 0, 4, 3, fx, fwA, 4, 2);
+            if (kt < 4) P8_STAMP(it);
+            P8_PHASE(rdW(fwA, 7), 1, 5, 3, fx, fwB, 4, 0);
+            if (kt < 4) P8_STAMP(it);
+        }
+        P8_STAMP(it);
         // epilogue of tile (m0, n0), beside the partner wave's MFMAs (waves 0-3 and 4-7 reach it half a phase apart)
-        prefetch_zr();
-        epi(0, 0, 0);
-        epi(1, 0, 2);
-        epi(2, 4, 2);
-        epi(3, 4, 0);
+        // The two wave groups reach this point half a phase apart, and whichever runs its epilogue holds the other at its next
+        // barrier: left alone, the two epilogues (and tile switches) run one after the other (~13k clocks per tile in the clock
+        // stamps).  One extra barrier each re-aligns them: waves 0-3 take theirs before the epilogue (it pairs with the barrier
+        // inside waves 4-7's last MFMA cluster), waves 4-7 after the tile switch (it pairs with the first barrier of waves 0-3's
+        // next phase) -- both groups then do their epilogues between the same two barriers, side by side.
+#if P8_REALIGN
+        if (!wr) P8_BARRIER();
+#endif
+#if !(P8_ABLATE & 1)
+        epilogue();
+#endif
+        P8_STAMP(it);
+#if P8_REALIGN
+        if (!have_next) { if (wr) P8_BARRIER(); break; }
+#else
         if (!have_next) break;
+#endif
         ++it;
         m0 = m1;
         n0 = n1;
@@ -342,6 +477,10 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         have_next = tile_origin(it + 1, m1, n1);
         dXn = mk_desc(a.X, m1, a.M, a.ldx, have_next);
         dWn = mk_desc(a.W, n1, a.N, a.ldw, have_next);
+        fetch_bias(n0);                  // the next tile's bias values: consumed by its epilogue a whole tile from now
+#if P8_REALIGN
+        if (wr) P8_BARRIER();
+#endif
     }
     P8_VMCNT(0);                         // no LDS-DMA may outlive the workgroup
     if (!wr) P8_BARRIER();               // balance the stagger barrier
@@ -369,18 +508,27 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess)
             MMGL_FAIL(MMGL_ERR_HIP, "gemm8p: hipGetDeviceProperties failed");
         n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-        const void* ks[6] = {(const void*)gemm8p_kernel<0, false>, (const void*)gemm8p_kernel<0, true>, (const void*)gemm8p_kernel<2, false>,
-                             (const void*)gemm8p_kernel<3, false>, (const void*)gemm8p_kernel<3, true>, (const void*)gemm8p_kernel<4, true>};
+        const void* ks[8] = {(const void*)gemm8p_kernel<0, false>, (const void*)gemm8p_kernel<0, true>, (const void*)gemm8p_kernel<1, false>,
+                             (const void*)gemm8p_kernel<1, true>,  (const void*)gemm8p_kernel<2, false>, (const void*)gemm8p_kernel<3, false>,
+                             (const void*)gemm8p_kernel<3, true>,  (const void*)gemm8p_kernel<4, true>};
         for (const void* kf : ks) {
-            hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+            hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_TOTAL);
             if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
     }
     const int grid = a.total < n_cu ? a.total : n_cu;
+    static const int stag_on = [] { const char* e = getenv("MMGL_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+    // a quarter of a tile time, ~11 clocks per unit of K (256 x 256 x K MACs at the sustained rate), when there are >= 3 rounds
+    a.stagger = (stag_on && a.total >= 3 * grid) ? (K * 11 * stag_on + 2048) / 4096 : 0;
+    a.trace = nullptr;
+#if P8_TRACE
+    if (const char* e = getenv("MMGL_P8_TRACE")) a.trace = (long long*)strtoull(e, nullptr, 0);
+#endif
     const bool zr = resid || zmask;
-#define P8_LAUNCH(A, Z) hipLaunchKernelGGL((gemm8p_kernel<A, Z>), dim3(grid), dim3(512), P8_LDS, st, a)
+#define P8_LAUNCH(A, Z) hipLaunchKernelGGL((gemm8p_kernel<A, Z>), dim3(grid), dim3(512), P8_LDS_TOTAL, st, a)
     switch (act) {
-        case 0: case 1: if (zr) P8_LAUNCH(0, true); else P8_LAUNCH(0, false); break;
+        case 0: if (zr) P8_LAUNCH(0, true); else P8_LAUNCH(0, false); break;
+        case 1: if (zr) P8_LAUNCH(1, true); else P8_LAUNCH(1, false); break;
         case 2: if (zr) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm8p: gelu(erf) with residual / zmask is not instantiated"); P8_LAUNCH(2, false); break;
         case 3: if (zr) P8_LAUNCH(3, true); else P8_LAUNCH(3, false); break;
         case 4: P8_LAUNCH(4, true); break;

@@ -8,6 +8,7 @@
 // 640..2176-key sequence needs.  Backward = flash backward: delta = rowsum(dO*O) pre-pass, a dQ kernel (loop over key
 // tiles per query tile) and a dK/dV kernel (loop over query tiles per key tile, no atomics, no global partials).
 #include "attn_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -760,8 +761,14 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
         }
     };
 
-    auto step = [&](int t0, v8 (&qa)[2][C::NDC], v8 (&ga)[2][C::NDC], float (&la)[2][4], float (&da)[2][4], v8 (&qn)[2][C::NDC],
-                    v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
+    // One 32-row step.  The tile's Q^T / dO^T fragments are fetched FIRST (tile write, transposed reads), so that the key-block
+    // loop below is free of fences: block sbl's exp / dS arithmetic (VALU) has the S / dP MFMAs of block sbl+1 and the
+    // dV / dK MFMAs of block sbl-1 to overlap with -- one wave per SIMD, so the overlap has to come from inside the wave.
+    // VALU diet: -lse and -delta enter as the MFMA C-inputs (acc = s - lse, dp - delta directly), the key-valid bias is one
+    // packed add, the causal select exists only in the two diagonal steps (DIAG).
+    auto step = [&](auto diag_tag, int t0, v8 (&qa)[2][C::NDC], v8 (&ga)[2][C::NDC], float (&la)[2][4], float (&da)[2][4],
+                    v8 (&qn)[2][C::NDC], v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
+        constexpr bool DIAG = decltype(diag_tag)::value;
         request(t0 + 32, qn, gn, ln, dn);
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
@@ -770,39 +777,9 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
                 *(v8*)(Qt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = qa[tb][dc];
                 *(v8*)(Gt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = ga[tb][dc];
             }
-        const bool diag = t0 < s0 + KW - 1;                         // some (row, key) pair with key > row (wave-uniform)
-        float lt[2][4];
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lt[tb][r] = (t0 + tb * 16 + g * 4 + r < T_) ? la[tb][r] * LOG2E : INFINITY;   // row past T: p = 0
-        v8 pB[NSBW], dsB[NSBW];
-#pragma unroll
-        for (int sbl = 0; sbl < NSBW; ++sbl) {
-            f32x4 pr[2], dsr[2];
-            const int s = s0 + sbl * 16 + x;
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
-                f32x4 sa = vzero<f32x4>(), pa = vzero<f32x4>();
-#pragma unroll
-                for (int dc = 0; dc < C::NDC; ++dc) {
-                    mma16(sa, qa[tb][dc], kf[sbl][dc]);
-                    mma16(pa, ga[tb][dc], vf[sbl][dc]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float e = fmaf(sa[r], LOG2E, kbias[sbl] - lt[tb][r]);
-                    if (diag) e = (s <= t0 + tb * 16 + g * 4 + r) ? e : -INFINITY;
-                    const float p = __builtin_amdgcn_exp2f(e);
-                    pr[tb][r] = p;
-                    dsr[tb][r] = p * (pa[r] - da[tb][r]);
-                }
-            }
-            pB[sbl] = pack8<T>(pr[0], pr[1]);
-            dsB[sbl] = pack8<T>(dsr[0], dsr[1]);
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        v8 gT[C::NDB], qT[C::NDB];
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db) {
             typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -812,24 +789,59 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
             const bf16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pg + 16 * LDT));
             const bf16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pq);
             const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pq + 16 * LDT));
-            const v8 gT = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-            const v8 qT = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            gT[db] = v8{g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+            qT[db] = v8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next step's tile write stays behind these reads
+        __builtin_amdgcn_wave_barrier();
+        f32x4 nl[2], nd[2];                                          // C-inputs: -lse (-inf for a row past T: p = 0), -delta
 #pragma unroll
-            for (int sbl = 0; sbl < NSBW; ++sbl) {
-                mma16(dva[db][sbl], gT, pB[sbl]);
-                mma16(dka[db][sbl], qT, dsB[sbl]);
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                nl[tb][r] = (t0 + tb * 16 + g * 4 + r < T_) ? -la[tb][r] : -INFINITY;
+                nd[tb][r] = -da[tb][r];
+            }
+#pragma unroll
+        for (int sbl = 0; sbl < NSBW; ++sbl) {
+            f32x4 pr[2], dsr[2];
+            const int s = s0 + sbl * 16 + x;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                f32x4 sa = nl[tb] + kbias[sbl], pa = nd[tb];
+#pragma unroll
+                for (int dc = 0; dc < C::NDC; ++dc) {
+                    mma16(sa, qa[tb][dc], kf[sbl][dc]);
+                    mma16(pa, ga[tb][dc], vf[sbl][dc]);
+                }
+                f32x4 e = sa * LOG2E;
+                if constexpr (DIAG) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[r] = (s <= t0 + tb * 16 + g * 4 + r) ? e[r] : -INFINITY;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[tb][r] = __builtin_amdgcn_exp2f(e[r]);
+                dsr[tb] = pr[tb] * pa;
+            }
+            const v8 pB = pack8<T>(pr[0], pr[1]), dsB = pack8<T>(dsr[0], dsr[1]);
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db) {
+                mma16(dva[db][sbl], gT[db], pB);
+                mma16(dka[db][sbl], qT[db], dsB);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     };
 
     v8 qA[2][C::NDC], gA[2][C::NDC], qB[2][C::NDC], gB[2][C::NDC];
     float lA[2][4], dA[2][4], lB[2][4], dB[2][4];
     request(s0, qA, gA, lA, dA);
-    for (int t0 = s0; t0 < T_; t0 += 64) {
-        step(t0, qA, gA, lA, dA, qB, gB, lB, dB);
-        if (t0 + 32 < T_) step(t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
+    typedef std::integral_constant<bool, true> on_diag;
+    typedef std::integral_constant<bool, false> off_diag;
+    step(on_diag(), s0, qA, gA, lA, dA, qB, gB, lB, dB);                           // rows s0 .. s0+63 can precede keys of this group
+    if (s0 + 32 < T_) step(on_diag(), s0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
+    for (int t0 = s0 + 64; t0 < T_; t0 += 64) {
+        step(off_diag(), t0, qA, gA, lA, dA, qB, gB, lB, dB);
+        if (t0 + 32 < T_) step(off_diag(), t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
     }
 #pragma unroll
     for (int sbl = 0; sbl < NSBW; ++sbl) {

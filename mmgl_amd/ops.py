@@ -677,7 +677,9 @@ def gemm_nt(x2, w, bias=None, residual=None, zmask=None, act=0, out_scale=1.0, K
     y = torch.empty(M, N, dtype=x2.dtype, device=x2.device) if out is None else out
     if M == 0:
         return y
-    _lib.call("mmgl_gemm_nt", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x2.element_size()),
+    _lib.call("mmgl_gemm_nt", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x2.element_size(),
+                                   tag=f"{M}x{N}x{K}" + ("+b" if bias is not None else "") + ("+z" if zmask is not None else "")
+                                       + ("+r" if residual is not None else "") + (f"+a{act}" if act else "")),
               ptr(x2), x2.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(residual), ptr(zmask), ptr(y), y.stride(0), M, N, K, act,
               float(out_scale), dtype_code(x2), stream_ptr())
     return y
