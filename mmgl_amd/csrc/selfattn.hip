@@ -13,19 +13,61 @@
 namespace {
 
 constexpr int KT = 64;            // keys per tile (NSB = 4)
+#ifndef SA_ABLATE
+#define SA_ABLATE 0               // timing experiments only (1: K/V tiles fetched once, 2: no per-tile barrier); never set in a shipped build
+#endif
 
 template <typename T, int D> struct SC : XC<T, D, 4, 1> {};
 
-// per-tile additive key bias in accumulator layout from the staged valid bytes (0 valid, -inf masked/absent)
-template <typename C> __device__ __forceinline__ void tile_bias(const uint8_t* vld, int g, f32x4 (&bias)[4]) {
+// per-tile additive key bias in accumulator layout from the staged valid bytes (0 valid, -inf masked/absent).  Returns true
+// (wave-uniform) when every key of the tile is valid: the bias is all zeros and the caller's masking code can be skipped.
+template <typename C> __device__ __forceinline__ bool tile_bias(const uint8_t* vld, int g, f32x4 (&bias)[4]) {
+    uint32_t w[4];
 #pragma unroll
-    for (int sb = 0; sb < 4; ++sb) {
-        const uint32_t w = *(const uint32_t*)(vld + sb * 16 + g * 4);
+    for (int sb = 0; sb < 4; ++sb) w[sb] = *(const uint32_t*)(vld + sb * 16 + g * 4);       // staged as exactly 0 / 1 per key
+    const bool lane_all = (w[0] & w[1] & w[2] & w[3]) == 0x01010101u;
+    if (__builtin_amdgcn_ballot_w64(!lane_all) == 0ull) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[sb][r] = ((w >> (8 * r)) & 0xffu) ? 0.f : -INFINITY;
+        for (int sb = 0; sb < 4; ++sb) bias[sb] = vzero<f32x4>();
+        return true;
     }
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[sb][r] = ((w[sb] >> (8 * r)) & 0xffu) ? 0.f : -INFINITY;
+    return false;
 }
 
+__device__ __forceinline__ f32x4 vmax4(const f32x4& a, const f32x4& b) { return __builtin_elementwise_max(a, b); }
+
+// One online-softmax step of a query row held as 16 scores per lane (4 key blocks x 4): new running max, P = exp2(...) in
+// place, the lane's partial row sum (kept as a 4-vector: packed adds, folded once at the end), the output accumulators
+// rescaled, P packed as the two B-operand fragments of the P.V product.  Written on 4-vectors so that hipcc emits the packed
+// fp32 forms (v_pk_fma / v_pk_add / v_pk_mul) and v_max3 chains: about a third fewer VALU instructions than the scalar form,
+// in kernels whose vector ALU is busier than their matrix pipe.
+template <typename T, int NDB>
+__device__ __forceinline__ void online_softmax_row(f32x4 (&s)[4], float& m, f32x4& lsum, f32x4 (&o)[NDB], typename Elem<T>::v8 (&pf)[2],
+                                                   bool guard_empty) {
+    const f32x4 m4 = vmax4(vmax4(vmax4(s[0], s[1]), s[2]), s[3]);
+    float tm = fmaxf(fmaxf(fmaxf(m4[0], m4[1]), m4[2]), m4[3]);
+    tm = xg_max(tm);
+    const float mn = fmaxf(m, tm);
+    const float mn2 = (guard_empty && mn == -INFINITY) ? 0.f : mn * LOG2E;      // row without any allowed key yet: keep p = 0
+    const float alpha = __builtin_amdgcn_exp2f(m * LOG2E - mn2);                // m = -inf -> 0
+    m = mn;
+    const f32x4 nm = {-mn2, -mn2, -mn2, -mn2};
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+        const f32x4 e = s[sb] * LOG2E + nm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[sb][r] = __builtin_amdgcn_exp2f(e[r]);
+    }
+    lsum = lsum * alpha + ((s[0] + s[1]) + (s[2] + s[3]));
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) o[db] *= alpha;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) pf[ks] = pack8<T>(s[2 * ks], s[2 * ks + 1]);
+}
 
 // Register-staged K / V tile (T14 split: the next tile's global loads are issued before the current tile's MFMAs and
 // written to LDS after them, so the HBM/L2 latency of a 64-key tile hides under compute).
@@ -47,6 +89,9 @@ template <typename T, typename C, bool K_ROWMAJOR, bool V_ROWMAJOR> struct TileS
     // branch-free form: rows past the end of the sequence / padding channels fall outside the descriptor and read as 0
     __device__ __forceinline__ void loadb(__amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv, uint32_t row_bytes,
                                           const uint8_t* valid_row, int s0, int T_) {
+#if SA_ABLATE & 1                           // timing experiment: only the first tile is fetched (results are wrong)
+        if (s0 > 0) return;
+#endif
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int id = threadIdx.x + i * 256, s = id / C::CPR, c = id % C::CPR;
@@ -67,7 +112,7 @@ template <typename T, typename C, bool K_ROWMAJOR, bool V_ROWMAJOR> struct TileS
             if constexpr (V_ROWMAJOR) *(v8*)(Vimg + s * C::LD + c * 8) = vr[i];
             else *(v8*)(Vimg + rf_idx<C>(s >> 4, c >> 2, (s & 15) + 16 * (c & 3))) = vr[i];
         }
-        if (threadIdx.x < KT) vld[threadIdx.x] = vb;
+        if (threadIdx.x < KT) vld[threadIdx.x] = vb ? (uint8_t)1 : (uint8_t)0;
     }
 };
 
@@ -112,12 +157,13 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
 #pragma unroll
         for (int dc = 0; dc < C::NDC; ++dc) qf[qt][dc] = buf_load8<T>(rq, row_off<T, C>(t0 + qt * 16 + x, rbq, dc * 32 + g * 8));
 
-    float m[C::QT], l[C::QT];
+    float m[C::QT];
+    f32x4 l[C::QT];
     f32x4 oacc[C::QT][C::NDB];
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
         m[qt] = -INFINITY;
-        l[qt] = 0.f;
+        l[qt] = vzero<f32x4>();
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db) oacc[qt][db] = vzero<f32x4>();
     }
@@ -162,29 +208,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
                     for (int r = 0; r < 4; ++r)
                         if (s0 + sb * 16 + g * 4 + r > t) sacc[qt][sb][r] = -INFINITY;
             }
-            float tm = fmaxf(fmaxf(sacc[qt][0][0], sacc[qt][0][1]), fmaxf(sacc[qt][0][2], sacc[qt][0][3]));
-#pragma unroll
-            for (int sb = 1; sb < 4; ++sb)
-                tm = fmaxf(tm, fmaxf(fmaxf(sacc[qt][sb][0], sacc[qt][sb][1]), fmaxf(sacc[qt][sb][2], sacc[qt][sb][3])));
-            tm = xg_max(tm);
-            const float mn = fmaxf(m[qt], tm);
-            const float mn2 = (mn == -INFINITY) ? 0.f : mn * LOG2E;      // row without any allowed key yet: keep p = 0
-            const float alpha = __builtin_amdgcn_exp2f(m[qt] * LOG2E - mn2);   // m = -inf -> 0
-            m[qt] = mn;
-            float ls = 0.f;
-#pragma unroll
-            for (int sb = 0; sb < 4; ++sb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qt][sb][r], LOG2E, -mn2));
-                    sacc[qt][sb][r] = p;
-                    ls += p;
-                }
-            l[qt] = l[qt] * alpha + ls;                       // per-lane partial; folded across the 4 lane groups at the end
-#pragma unroll
-            for (int db = 0; db < C::NDB; ++db) oacc[qt][db] *= alpha;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) pf[qt][ks] = pack8<T>(sacc[qt][2 * ks], sacc[qt][2 * ks + 1]);
+            online_softmax_row<T, C::NDB>(sacc[qt], m[qt], l[qt], oacc[qt], pf[qt], true);
         }
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db)
@@ -198,12 +222,14 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
             }
         }
         if (j + 1 < nkt) stg.store(Kimg((j + 1) & 1), Vimg((j + 1) & 1), Vld((j + 1) & 1));
+#if !(SA_ABLATE & 2)
         __syncthreads();
+#endif
     }
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
         const int t = t0 + qt * 16 + x;
-        const float lt = xg_sum(l[qt]);
+        const float lt = xg_sum((l[qt][0] + l[qt][1]) + (l[qt][2] + l[qt][3]));
         const float inv = __builtin_amdgcn_rcpf(lt);
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db) buf_store4<T>(ro, row_off<T, C>(t, row_bytes, db * 16 + g * 4), oacc[qt][db] * inv);
@@ -256,12 +282,13 @@ __global__ __launch_bounds__(256) void encattn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int dc = 0; dc < C::NDC; ++dc) qf[qt][dc] = buf_load8<T>(rq, row_off<T, C>(t0 + qt * 16 + x, rb_in, dc * 32 + g * 8));
 
-    float m[C::QT], l[C::QT];
+    float m[C::QT];
+    f32x4 l[C::QT];
     f32x4 oacc[C::QT][C::NDB];
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
         m[qt] = -INFINITY;
-        l[qt] = 0.f;
+        l[qt] = vzero<f32x4>();
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db) oacc[qt][db] = vzero<f32x4>();
     }
@@ -291,31 +318,8 @@ __global__ __launch_bounds__(256) void encattn_fwd_kernel(const T* __restrict__ 
         }
         v8 pf[C::QT][2];
 #pragma unroll
-        for (int qt = 0; qt < C::QT; ++qt) {
-            float tm = fmaxf(fmaxf(sacc[qt][0][0], sacc[qt][0][1]), fmaxf(sacc[qt][0][2], sacc[qt][0][3]));
-#pragma unroll
-            for (int sb = 1; sb < 4; ++sb)
-                tm = fmaxf(tm, fmaxf(fmaxf(sacc[qt][sb][0], sacc[qt][sb][1]), fmaxf(sacc[qt][sb][2], sacc[qt][sb][3])));
-            tm = xg_max(tm);
-            const float mn = fmaxf(m[qt], tm);                // finite from tile 0 on: every tile holds >= 1 real key
-            const float mn2 = mn * LOG2E;
-            const float alpha = __builtin_amdgcn_exp2f(m[qt] * LOG2E - mn2);
-            m[qt] = mn;
-            float ls = 0.f;
-#pragma unroll
-            for (int sb = 0; sb < 4; ++sb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qt][sb][r], LOG2E, -mn2));
-                    sacc[qt][sb][r] = p;
-                    ls += p;
-                }
-            l[qt] = l[qt] * alpha + ls;
-#pragma unroll
-            for (int db = 0; db < C::NDB; ++db) oacc[qt][db] *= alpha;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) pf[qt][ks] = pack8<T>(sacc[qt][2 * ks], sacc[qt][2 * ks + 1]);
-        }
+        for (int qt = 0; qt < C::QT; ++qt)                    // the running max is finite from tile 0 on: every tile holds >= 1 real key
+            online_softmax_row<T, C::NDB>(sacc[qt], m[qt], l[qt], oacc[qt], pf[qt], false);
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
@@ -327,12 +331,14 @@ __global__ __launch_bounds__(256) void encattn_fwd_kernel(const T* __restrict__ 
                 for (int qt = 0; qt < C::QT; ++qt) mma16(oacc[qt][db], vt, pf[qt][ks]);
             }
         if (j + 1 < nkt) stg.store(Kimg((j + 1) & 1), Vimg((j + 1) & 1), Vld((j + 1) & 1));
+#if !(SA_ABLATE & 2)
         __syncthreads();
+#endif
     }
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
         const int t = t0 + qt * 16 + x;
-        const float inv = __builtin_amdgcn_rcpf(xg_sum(l[qt]));
+        const float inv = __builtin_amdgcn_rcpf(xg_sum((l[qt][0] + l[qt][1]) + (l[qt][2] + l[qt][3])));
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db) buf_store4<T>(ro, row_off<T, C>(t, rb_out, db * 16 + g * 4), oacc[qt][db] * inv);
     }
@@ -436,11 +442,16 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
         const bool diag = s0 + KT - 1 > t0;
         v8 dsf[C::QT][2];
         {
+            // VALU diet: -delta enters as the C-input of the dP product (acc = dP - delta), the exp argument and dS are packed
+            // 4-vector ops, the causal select exists only on diagonal tiles
             f32x4 sacc[C::QT][4], pacc[C::QT][4];
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) {
 #pragma unroll
-                for (int qt = 0; qt < C::QT; ++qt) { sacc[qt][sb] = bias[sb]; pacc[qt][sb] = vzero<f32x4>(); }
+                for (int qt = 0; qt < C::QT; ++qt) {
+                    sacc[qt][sb] = bias[sb];
+                    pacc[qt][sb] = f32x4{-dlt[qt], -dlt[qt], -dlt[qt], -dlt[qt]};
+                }
 #pragma unroll
                 for (int dc = 0; dc < C::NDC; ++dc) {
                     v8 kf;
@@ -457,15 +468,19 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
 #pragma unroll
             for (int qt = 0; qt < C::QT; ++qt) {
                 const int t = t0 + qt * 16 + x;
+                const f32x4 nl = {-lse2[qt], -lse2[qt], -lse2[qt], -lse2[qt]};
 #pragma unroll
-                for (int sb = 0; sb < 4; ++sb)
+                for (int sb = 0; sb < 4; ++sb) {
+                    f32x4 e = sacc[qt][sb] * LOG2E + nl;
+                    if (diag) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float sc = sacc[qt][sb][r];
-                        if (diag && (s0 + sb * 16 + g * 4 + r > t)) sc = -INFINITY;
-                        const float p = __builtin_amdgcn_exp2f(fmaf(sc, LOG2E, -lse2[qt]));
-                        sacc[qt][sb][r] = p * (pacc[qt][sb][r] - dlt[qt]);
+                        for (int r = 0; r < 4; ++r) e[r] = (s0 + sb * 16 + g * 4 + r > t) ? -INFINITY : e[r];
                     }
+                    f32x4 p4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p4[r] = __builtin_amdgcn_exp2f(e[r]);
+                    sacc[qt][sb] = p4 * pacc[qt][sb];
+                }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) dsf[qt][ks] = pack8<T>(sacc[qt][2 * ks], sacc[qt][2 * ks + 1]);
             }
@@ -482,7 +497,9 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
             }
         }
         if (j + 1 < nkt) stg.store(Kimg((j + 1) & 1), Vimg((j + 1) & 1), Vld((j + 1) & 1));
+#if !(SA_ABLATE & 2)
         __syncthreads();
+#endif
     }
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
