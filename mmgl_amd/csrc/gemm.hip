@@ -313,6 +313,11 @@ inline int tune_gemm_8p() {
     static const int v = [] { const char* e = getenv("MMGL_GEMM_8P"); return e ? atoi(e) : 1; }();
     return v;
 }
+// few-tile shapes (>= 24 tiles: below that even 8 splits leave most of the chip idle and the 128x128 kernel's 4x finer tiles win)
+inline bool gemm8p_use_splits(int M, int N, int K) {
+    static const int on = [] { const char* e = getenv("MMGL_GEMM_8P_SPLITK"); return e ? atoi(e) : 1; }();
+    return on && cdiv(M, 256) * cdiv(N, 256) >= 24 && gemm8p_splits(M, N, K) > 0;
+}
 inline int tune_gemm_8p_min_tiles() {
     static const int v = [] { const char* e = getenv("MMGL_GEMM_8P_MIN_TILES"); return e ? atoi(e) : 160; }();
     return v;
@@ -397,7 +402,8 @@ int launch_gemm(const T* X, const T* W, T* Y, const T* bias, int M, int N, int K
         MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm: K (%d) must be a multiple of %d and N (%d) of 4", K, VN, N);
     if constexpr (sizeof(T) == 2) {
         // persistent ping-pong kernel (gemm8p.hip) whenever the shape gives it enough 256x256 tiles
-        if (!X2 && !accumulate && tune_gemm_8p() && gemm8p_supported(M, N, K, K, K, N) && cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles()) {
+        if (!X2 && !accumulate && tune_gemm_8p() && gemm8p_supported(M, N, K, K, K, N) &&
+            (cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles() || gemm8p_use_splits(M, N, K))) {
             if (zmask_done) *zmask_done = zmask != nullptr;
             return launch_gemm8p((const bf16*)X, K, (const bf16*)W, K, (bf16*)Y, N, (const bf16*)bias, nullptr, (const bf16*)zmask, M, N, K, act, scale, st);
         }
@@ -1215,7 +1221,7 @@ extern "C" int mmgl_gated_residual_fwd(const void* residual, const void* x, cons
 
 extern "C" int mmgl_gemm_nt_fast(int M, int N, int K, int ldx, int ldw, int ldy, int dtype) {
     return dtype == MMGL_BF16 && tune_gemm_8p() && gemm8p_supported(M, N, K, ldx, ldw, ldy) &&
-           cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles();
+           (cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles() || gemm8p_use_splits(M, N, K));
 }
 
 extern "C" int mmgl_gemm_nt(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, const void* zmask,

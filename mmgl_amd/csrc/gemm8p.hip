@@ -52,6 +52,8 @@ struct P8Args {
     float scale;
     int act;
     int tiles_m, tiles_n, total;
+    int nsplit;            // K splits per output tile (1 = none): work item = (tile, split), fp32 partial tiles into `part`
+    float* part;           // [nsplit][M][N] fp32 (ACT = 5 kernels)
     int stagger;           // start delay per CU group in units of 4096 clocks (0 = none)
     long long* trace;      // timing experiments only (P8_TRACE builds): [8 waves][64] clock stamps of workgroup 0
 };
@@ -116,28 +118,34 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int x = lane & 15, g = lane >> 4;
-    const int K = a.K, nk = K >> 6;
+    int nk = a.K >> 6;                         // 64-wide K tiles of the current work item (varies by item under a K split)
 
     // ---- persistent tile schedule: in every round of gridDim.x tiles, XCD j (blocks b % 8 == j) takes 32 consecutive
     // virtual ids = one 8 x 4 group of tiles (grouped_tile): activation K slices are shared by 4 workgroups of one L2
     const int G = gridDim.x;
     const int wg = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    auto tile_origin = [&](int it, int& m0, int& n0) -> bool {
+    // work item -> (tile origin, first K element, K tiles): with a K split the K range is cut into nsplit runs of whole
+    // 128-wide steps (the first K/128 % nsplit runs one step longer)
+    auto tile_origin = [&](int it, int& m0, int& n0, int& k0, int& nki, int& sp) -> bool {
         const int v = it * G + wg;
-        if (v >= a.total) return false;
+        if (v >= a.total * a.nsplit) return false;
         int tm, tn;
-        grouped_tile(v, a.tiles_m, a.tiles_n, tm, tn);
+        sp = v % a.nsplit;
+        grouped_tile(v / a.nsplit, a.tiles_m, a.tiles_n, tm, tn);
         m0 = tm * 256;
         n0 = tn * 256;
+        const int units = a.K >> 7, base = units / a.nsplit, rem = units % a.nsplit;
+        k0 = (sp * base + (sp < rem ? sp : rem)) * 128;
+        nki = (base + (sp < rem ? 1 : 0)) * 2;
         return true;
     };
     // rows [row0, rows) of an operand with row stride ld: everything past the last row reads as zero.  (A K tile may run past
     // the end of a ROW when the caller pads K -- lm_head's dgrad contracts over V = 50272 -- and then reads the start of the next
     // row: finite values that meet the zero padding of the other operand.)
-    auto mk_desc = [&](const bf16* base, int row0, int rows, int ld, bool valid) {
-        long long rem = valid ? (long long)(rows - row0) * ld * 2 : 0;
+    auto mk_desc = [&](const bf16* base, int row0, int rows, int ld, int k0, bool valid) {
+        long long rem = valid ? (long long)(rows - row0) * ld * 2 - (long long)k0 * 2 : 0;
         if (rem > 0xffffffffLL) rem = 0xffffffffLL;
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (valid ? (size_t)row0 * ld : 0)), 0, (int)(unsigned)rem, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (valid ? (size_t)row0 * ld + k0 : 0)), 0, (int)(unsigned)rem, 0x00020000);
     };
 
     // ---- staging offsets: unit type 0 Xa, 1 Wb, 2 Xb, 3 Wa; each wave moves pieces `wave` and `wave + 8` (8 LDS rows each)
@@ -209,12 +217,12 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         }                                                                                      \
     } while (0)
 
-    int m0 = 0, n0 = 0, m1 = 0, n1 = 0;
+    int m0 = 0, n0 = 0, m1 = 0, n1 = 0, k0 = 0, k1 = 0, nk1 = 0, sp0 = 0, sp1 = 0;
     int it = 0;
-    if (!tile_origin(0, m0, n0)) return;
-    bool have_next = tile_origin(1, m1, n1);
-    __amdgpu_buffer_rsrc_t dXc = mk_desc(a.X, m0, a.M, a.ldx, true), dWc = mk_desc(a.W, n0, a.N, a.ldw, true);
-    __amdgpu_buffer_rsrc_t dXn = mk_desc(a.X, m1, a.M, a.ldx, have_next), dWn = mk_desc(a.W, n1, a.N, a.ldw, have_next);
+    if (!tile_origin(0, m0, n0, k0, nk, sp0)) return;
+    bool have_next = tile_origin(1, m1, n1, k1, nk1, sp1);
+    __amdgpu_buffer_rsrc_t dXc = mk_desc(a.X, m0, a.M, a.ldx, k0, true), dWc = mk_desc(a.W, n0, a.N, a.ldw, k0, true);
+    __amdgpu_buffer_rsrc_t dXn = mk_desc(a.X, m1, a.M, a.ldx, k1, have_next), dWn = mk_desc(a.W, n1, a.N, a.ldw, k1, have_next);
 
     // ---- epilogue plumbing.  Lane (x, g) owns, for each of its 8 rows m = m0 + wr*128 + 16 J + x, the columns
     // n = n0 + wc*64 + 32 (t >> 1) + 8 g + 4 (t & 1) + r.  The lane's 16 bias values are fetched at the top of the tile's last K-tile pair, five
@@ -241,6 +249,29 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     // converted bf16 pairs (a negative bf16 is a negative int16).  ZR kernels request the 16 zmask (else residual) vectors of
     // the tile up front: one exposed memory latency per tile instead of one per quadrant.
     auto epilogue = [&]() __attribute__((always_inline)) {
+        if constexpr (ACT == 5) {
+            // K-split work item: the raw fp32 accumulators of this split go to part[sp][m][n]; bias / activation / masks are
+            // applied by p8_splitk_finish_kernel when it folds the splits
+            const int ln = p8_lane();
+            const int ncol_l = wc * 64 + 8 * (ln >> 4);
+            const bool ok0 = n0 + ncol_l < a.N, ok1 = n0 + ncol_l + 32 < a.N;
+            const unsigned base = (unsigned)(((wr * 128 + (ln & 15)) * a.N + n0 + ncol_l) * 4);
+            const unsigned rstep = (unsigned)(16 * a.N * 4);
+            long long rem = (long long)(a.M - m0) * a.N * 4;
+            if (rem > 0xffffffffLL) rem = 0xffffffffLL;
+            const __amdgpu_buffer_rsrc_t dP = __builtin_amdgcn_make_buffer_rsrc((void*)(a.part + ((size_t)sp0 * a.M + m0) * a.N), 0, (int)(unsigned)rem, 0x00020000);
+#pragma unroll
+            for (int T0 = 0; T0 < 4; T0 += 2)
+#pragma unroll
+                for (int J = 0; J < 8; ++J) {
+                    const unsigned off = (T0 ? ok1 : ok0) ? base + (unsigned)J * rstep + (unsigned)(64 * T0) : 0xffffffffu;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, acc[T0][J]), dP, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, acc[T0 + 1][J]), dP, off == 0xffffffffu ? off : off + 16, 0, 0);
+                    acc[T0][J] = vzero<f32x4>();
+                    acc[T0 + 1][J] = vzero<f32x4>();
+                }
+            return;
+        }
         const int ln = p8_lane();
         const int ncol_l = wc * 64 + 8 * (ln >> 4);          // first column of this lane inside the tile (fragment rows 0, 1)
         const bool col_ok0 = n0 + ncol_l < a.N, col_ok1 = n0 + ncol_l + 32 < a.N;
@@ -472,11 +503,13 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         ++it;
         m0 = m1;
         n0 = n1;
+        nk = nk1;
+        sp0 = sp1;
         dXc = dXn;
         dWc = dWn;
-        have_next = tile_origin(it + 1, m1, n1);
-        dXn = mk_desc(a.X, m1, a.M, a.ldx, have_next);
-        dWn = mk_desc(a.W, n1, a.N, a.ldw, have_next);
+        have_next = tile_origin(it + 1, m1, n1, k1, nk1, sp1);
+        dXn = mk_desc(a.X, m1, a.M, a.ldx, k1, have_next);
+        dWn = mk_desc(a.W, n1, a.N, a.ldw, k1, have_next);
         fetch_bias(n0);                  // the next tile's bias values: consumed by its epilogue a whole tile from now
 #if P8_REALIGN
         if (wr) P8_BARRIER();
@@ -486,7 +519,66 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     if (!wr) P8_BARRIER();               // balance the stagger barrier
 }
 
+// fold the K splits of ACT = 5 work items and apply the epilogue:  Y = act((sum_s part[s] + bias) * scale) (zmask, + resid)
+__global__ __launch_bounds__(256) void p8_splitk_finish_kernel(const float* __restrict__ part, bf16* __restrict__ Y, const bf16* __restrict__ bias,
+                                                               const bf16* __restrict__ resid, const bf16* __restrict__ zmask, int M, int N, int ldy,
+                                                               int nsplit, int act, float scale) {
+    const size_t nv = (size_t)M * (N / 8), plane = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        const size_t m = i / (N / 8);
+        const int n = (int)(i - m * (N / 8)) * 8;
+        const float* p = part + m * N + n;
+        f32x4 lo = *(const f32x4*)p, hi = *(const f32x4*)(p + 4);
+        for (int sp = 1; sp < nsplit; ++sp) {
+            lo += *(const f32x4*)(p + sp * plane);
+            hi += *(const f32x4*)(p + sp * plane + 4);
+        }
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (bias) {
+            const bf16x8 b = *(const bf16x8*)(bias + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)b[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = v[e] * scale;
+            switch (act) {
+                case 1: t = p8_act<1>(t); break;
+                case 2: t = p8_act<2>(t); break;
+                case 3: t = p8_act<3>(t); break;
+                case 4: t = p8_act<4>(t); break;
+                default: break;
+            }
+            v[e] = t;
+        }
+        const size_t yo = m * (size_t)ldy + n;
+        if (zmask) {
+            const bf16x8 z = *(const bf16x8*)(zmask + yo);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = ((float)z[e] > 0.f) ? v[e] : 0.f;
+        }
+        if (resid) {
+            const bf16x8 r = *(const bf16x8*)(resid + yo);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+        }
+        f32x8 o8 = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+        *(bf16x8*)(Y + yo) = __builtin_convertvector(o8, bf16x8);
+    }
+}
+
 }  // namespace
+
+// K splits for an output with too few 256x256 tiles to fill the chip (0 = none): about one work item per CU, each at least
+// two 128-wide K steps.  N % 8 == 0 is implied by gemm8p_supported.
+int gemm8p_splits(int M, int N, int K) {
+    const int tiles = cdiv(M, 256) * cdiv(N, 256), units = K / 128;
+    if (tiles >= 160 || units < 24) return 0;          // measured: a gain from K = 3072 up (K = 8192: 129 -> 92 us at M = 2560), a loss at K <= 2048
+    int s = (224 + tiles - 1) / tiles;
+    if (s > 8) s = 8;
+    if (s > units / 2) s = units / 2;
+    return s >= 2 ? s : 0;
+}
 
 bool gemm8p_supported(int M, int N, int K, int ldx, int ldw, int ldy) {
     return M > 0 && N > 0 && K >= 256 && K % 128 == 0 && N % 16 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0 &&
@@ -501,6 +593,8 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
     a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.resid = resid; a.zmask = zmask;
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.scale = scale; a.act = act;
     a.tiles_m = cdiv(M, 256); a.tiles_n = cdiv(N, 256); a.total = a.tiles_m * a.tiles_n;
+    a.nsplit = 1;
+    a.part = nullptr;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -508,13 +602,42 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess)
             MMGL_FAIL(MMGL_ERR_HIP, "gemm8p: hipGetDeviceProperties failed");
         n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-        const void* ks[8] = {(const void*)gemm8p_kernel<0, false>, (const void*)gemm8p_kernel<0, true>, (const void*)gemm8p_kernel<1, false>,
+        const void* ks[9] = {(const void*)gemm8p_kernel<0, false>, (const void*)gemm8p_kernel<0, true>, (const void*)gemm8p_kernel<1, false>,
                              (const void*)gemm8p_kernel<1, true>,  (const void*)gemm8p_kernel<2, false>, (const void*)gemm8p_kernel<3, false>,
-                             (const void*)gemm8p_kernel<3, true>,  (const void*)gemm8p_kernel<4, true>};
+                             (const void*)gemm8p_kernel<3, true>,  (const void*)gemm8p_kernel<4, true>,  (const void*)gemm8p_kernel<5, false>};
         for (const void* kf : ks) {
             hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_TOTAL);
             if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
+    }
+    // few-tile outputs (the reference's batch of 4: M = 2560): K-split work items with fp32 partial tiles, folded (with the whole
+    // epilogue) by p8_splitk_finish_kernel.  The partial buffer is a process-wide scratch area: launches are ordered by `st`
+    // (one stream, like every caller of this library); it only grows.
+    const int nsplit = gemm8p_splits(M, N, K);
+    if (nsplit) {
+        static float* part = nullptr;
+        static size_t part_bytes = 0;
+        const size_t need = (size_t)nsplit * M * N * sizeof(float);
+        if (need > part_bytes) {
+            if (part && hipStreamSynchronize(st) == hipSuccess) (void)hipFree(part);
+            part = nullptr;
+            part_bytes = 0;
+            if (hipMalloc((void**)&part, need) != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "gemm8p: cannot allocate %zu B of split-K scratch", need);
+            part_bytes = need;
+        }
+        a.nsplit = nsplit;
+        a.part = part;
+        const int items = a.total * nsplit, g = items < n_cu ? items : n_cu;
+        a.stagger = 0;
+        a.trace = nullptr;
+        hipLaunchKernelGGL((gemm8p_kernel<5, false>), dim3(g), dim3(512), P8_LDS_TOTAL, st, a);
+        MMGL_CHECK_LAUNCH("gemm8p (K split)");
+        const size_t nv = (size_t)M * (N / 8);
+        int blocks = (int)((nv + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(p8_splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, part, Y, bias, resid, zmask, M, N, ldy, nsplit, act, scale);
+        MMGL_CHECK_LAUNCH("gemm8p split-K finish");
+        return MMGL_OK;
     }
     const int grid = a.total < n_cu ? a.total : n_cu;
     static const int stag_on = [] { const char* e = getenv("MMGL_GEMM_STAGGER"); return e ? atoi(e) : 0; }();

@@ -41,6 +41,9 @@ CASES = [
     (20003, 3072, 768, 3, True, True, False, 1.0),       # quick-GELU + residual: CLIP FFN
     (5000, 50272, 2048, 0, False, False, False, 1.0),    # lm_head forward (N = vocab, last tile 96 columns)
     (4099, 4096, 11008, 4, True, True, True, 1.0),       # config-5 dims, tanh-GELU, everything at once
+    (2560, 2048, 8192, 1, True, False, False, 1.0),      # the reference's batch of 4 (80 tiles): K-split work items + finish kernel
+    (2600, 2048, 6144, 3, True, True, False, 0.5),       # uneven K splits (48 steps over 3), ragged M, residual, scale
+    (2560, 2064, 3072, 0, False, False, True, 1.0),      # K split with a ragged last column tile and the zmask applied by the finish kernel
     (1024, 512, 256, 1, True, False, False, 1.0),        # small: composed path (128x128 kernel + elementwise)
     (300, 96, 64, 2, True, True, True, 2.0),             # tiny, ragged K tile: composed path
 ]

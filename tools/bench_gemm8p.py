@@ -111,6 +111,10 @@ if __name__ == "__main__":
     ok &= check(8192, 2048, 8192, zmask=True, bias=False, scale=0.5)
     ok &= check(4099, 3072, 768, act=4, resid=True, zmask=True)
     ok &= check(1024, 512, 256)                               # small: composed fallback
+    ok &= check(2560, 2048, 2048, act=1)                      # few tiles (the reference's batch of 4): K-split work items
+    ok &= check(2560, 2048, 8192, zmask=True, bias=False)
+    ok &= check(2600, 2048, 6144, resid=True, act=3)          # uneven splits (48 K steps over 3), ragged M
+    ok &= check(6500, 768, 3072, act=2)
     print("ALL OK" if ok else "SOME FAILED", flush=True)
     if not quick:
         for (M, N, K, act) in [(40960, 2048, 2048, 0), (40960, 6144, 2048, 0), (40960, 8192, 2048, 1), (40960, 2048, 8192, 0),
