@@ -11,7 +11,8 @@
 // Bb: rb 64-127, Aa-of-the-next-K-tile: ra 0-31), issued 6 phases ahead, counted vmcnt, stream continuous across work items.
 // Work item = (output tile, K split): a 2048 x 2048 weight is only 64 tiles, so the M rows are cut into `nsplit` ranges whose
 // fp32 partial tiles a fixed-order reduce folds afterwards (deterministic, no atomics).
-// Needs RA % 256 == 0, RB % 256 == 0, (M / nsplit) % 128 == 0 and >= 256.
+// Needs (M / nsplit) % 128 == 0 and >= 256; RA % 256 == 0 and RB % 256 == 0 under a K split (unsplit: multiples of 8, ragged last
+// tiles are masked at the store).
 #include "common.h"
 #include "gemm8p.h"
 
@@ -79,7 +80,9 @@ __global__ __launch_bounds__(512) void gemm8p_tt_kernel(T8Args a) {
     };
     auto mk_desc = [&](const bf16* base, int col0, int split, int ld, bool valid) {
         const size_t off = (size_t)split * a.Mk * ld + col0;
-        long long rem = valid ? (long long)a.Mk * ld * 2 : 0;
+        // exact end of this split's rows: in a ragged last column tile the columns past the matrix wrap into the next row (finite
+        // values whose products land in output rows / columns that are never stored) and read as zero past the last row
+        long long rem = valid ? ((long long)a.Mk * ld - col0) * 2 : 0;
         if (rem > 0xffffffffLL) rem = 0xffffffffLL;
         return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (valid ? off : 0)), 0, (int)(unsigned)rem, 0x00020000);
     };
@@ -150,9 +153,10 @@ __global__ __launch_bounds__(512) void gemm8p_tt_kernel(T8Args a) {
             const size_t rb = (size_t)(b0 + wr * 128 + j * 16 + x);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const size_t o = rb * a.RA + a0 + wc * 64 + t * 16 + g * 4;
+                const int ca = a0 + wc * 64 + t * 16 + g * 4;
+                const size_t o = rb * a.RA + ca;
                 if (a.nsplit > 1) *(f32x4*)(a.part + (size_t)sp * a.RA * a.RB + o) = acc[t][j];
-                else {
+                else if (rb < (size_t)a.RB && ca < a.RA) {            // ragged last tiles (nsplit == 1 only)
                     f32x4 v = acc[t][j] * a.scale;
                     if (a.accumulate) {
                         const bf16x4 ov = *(const bf16x4*)(a.Out + o);
@@ -238,7 +242,9 @@ __global__ __launch_bounds__(512) void gemm8p_tt_kernel(T8Args a) {
 // Few-tile outputs (a 2048 x 2048 weight: 64 tiles; a rank-padded LoRA factor: 8) take up to 16 splits and run with as few as
 // 64 work items -- still far ahead of the non-persistent 128 x 128 kernel, which has no K split at all.
 int gemm8p_tt_splits(int RA, int RB, int M) {
-    if (RA % 256 || RB % 256 || M % 128) return 0;
+    if (M % 128) return 0;
+    if (RA % 256 || RB % 256)                        // ragged outputs (lm_head: 50272 rows): unsplit only, when the tiles fill the chip
+        return (RA % 8 == 0 && RB % 8 == 0 && M >= 256 && cdiv(RA, 256) * cdiv(RB, 256) >= 192) ? 1 : 0;
     const int tiles = (RA / 256) * (RB / 256);
     int best = 0;
     for (int s = 1; s <= 16; s *= 2) {
@@ -251,13 +257,13 @@ int gemm8p_tt_splits(int RA, int RB, int M) {
 
 int launch_gemm8p_tt(const bf16* A, int lda, const bf16* B, int ldb, bf16* Out, float* part, int RA, int RB, int M, int nsplit, float scale,
                      int accumulate, hipStream_t st) {
-    if (nsplit < 1 || RA % 256 || RB % 256 || M % (128 * nsplit) || M / nsplit < 256 || (nsplit > 1 && !part))
+    if (nsplit < 1 || ((RA % 256 || RB % 256) && (nsplit > 1 || RA % 8 || RB % 8)) || M % (128 * nsplit) || M / nsplit < 256 || (nsplit > 1 && !part))
         MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm8p_tt: shape RA=%d RB=%d M=%d nsplit=%d not supported", RA, RB, M, nsplit);
     if ((long long)M * lda * 2 >= 0xffffffffLL || (long long)M * ldb * 2 >= 0xffffffffLL)
         MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm8p_tt: operand larger than 4 GiB");
     T8Args a;
     a.A = A; a.B = B; a.Out = Out; a.part = part; a.RA = RA; a.RB = RB; a.Mk = M / nsplit; a.lda = lda; a.ldb = ldb; a.scale = scale;
-    a.accumulate = accumulate; a.tiles_a = RA / 256; a.tiles_b = RB / 256; a.nsplit = nsplit; a.total = a.tiles_a * a.tiles_b * nsplit;
+    a.accumulate = accumulate; a.tiles_a = cdiv(RA, 256); a.tiles_b = cdiv(RB, 256); a.nsplit = nsplit; a.total = a.tiles_a * a.tiles_b * nsplit;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;

@@ -385,11 +385,25 @@ class _Linear(torch.autograd.Function):
         want_w = ctx.need[1] or ctx.need[2]
         dw = torch.empty_like(w) if want_w else None
         db = torch.empty(N, dtype=x2.dtype, device=x2.device) if ctx.need[2] else None
+        dx_done = None
+        if (dx is not None and N % 128 and act == _lib.ACT_NONE and not ctx.mask_dx and x2.dtype == torch.bfloat16 and K % 8 == 0
+                and N % 8 == 0):
+            # a contraction length that is no multiple of 128 (a trainable lm_head: N = vocab = 50272) has no large-tile dgrad
+            # in mmgl_linear_bwd; W^T zero-padded to the next multiple (built per call: the weight is being trained) puts it on
+            # the persistent kernel, dy read with its own row stride (frozen_dgrad's trick)
+            npad = N + (-N) % 128
+            if lib().mmgl_gemm_nt_fast(M, K, npad, N, npad, K, code):
+                wt = torch.zeros(K, npad, dtype=w.dtype, device=w.device)
+                wt[:, :N] = w.t()
+                gemm_nt(dy2, wt, out_scale=out_scale, K=npad, out=dx)
+                dx_done, dx = dx, None
         ws = _ws(lib().mmgl_linear_bwd_workspace(M, N, K, act, code), x2.device)
         _lib.call("mmgl_linear_bwd", dict(flops=2.0 * M * N * K * (int(dx is not None) + int(dw is not None)),
                                          bytes=float(M * K + N * K + M * N) * x2.element_size()),
                   ptr(dy2), ptr(y), ptr(x2), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), ws.numel(), M, N, K, act, out_scale, 0,
                   int(ctx.mask_dx), code, stream_ptr())
+        if dx_done is not None:
+            dx = dx_done
         if dx is not None:
             dx = dx.view(shape)
         dw = dw.to(wdt) if (dw is not None and ctx.need[1]) else None

@@ -239,7 +239,9 @@ def test_linear(M, N, K, dtype, act):
 
 @pytest.mark.parametrize("act", ["none", "relu"])
 @pytest.mark.parametrize("M,N,K", [(8192 - 64, 4096, 4096),      # big forward (ragged M), big dgrad, big wgrad (256 tiles)
-                                   (8192, 2048, 2048)])          # 64-tile weight gradient: split-K x4 + fp32 reduce
+                                   (8192, 2048, 2048),           # 64-tile weight gradient: split-K x4 + fp32 reduce
+                                   (8192, 6504, 2048)])          # trainable lm_head-like: N no multiple of 128 / 256 -> zero-padded
+                                                                 # contraction in dgrad, ragged last tile row in the weight gradient
 def test_linear_big_tile_kernels(act, M, N, K):
     """Shapes large enough for the 256x256 kernels (>= 512 block tiles in forward AND in dgrad), ragged in M and N, checked
     against a CUDA fp32 matmul of the same bf16 inputs (the CPU reference of the small cases would take minutes here)."""
