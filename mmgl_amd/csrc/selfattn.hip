@@ -7,6 +7,9 @@
 // between lanes, V^T / K^T fragments via ds_read_b64_tr_b16), plus the online-softmax loop over 64-key tiles that a
 // 640..2176-key sequence needs.  Backward = flash backward: delta = rowsum(dO*O) pre-pass, a dQ kernel (loop over key
 // tiles per query tile) and a dK/dV kernel (loop over query tiles per key tile, no atomics, no global partials).
+#ifdef SA_QT_FORCE                  // timing experiments: 16-row (1) / 32-row (2) query tiles per wave in this file only
+#define MMGL_XATTN_QT_FORCE SA_QT_FORCE
+#endif
 #include "attn_common.h"
 #include <type_traits>
 
