@@ -715,7 +715,9 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
 // dV += P^T dO, dK += dS^T Q.  Branch-free body: bounds by buffer descriptors, masks by selects feeding exp2(-inf) = 0.
 // No barrier, no cross-wave reduction: every dK / dV element is produced by one wave.
 // NSBW = 16-key blocks per wave: 4 (64 keys) up to D = 64, 2 (32 keys) at D = 128 (the dK / dV accumulators are NSBW * D / 4 registers each)
-template <int D, int NSBW>
+// DB: two register sets for the Q / dO rows (the next tile in flight during this one: what a lone wave per SIMD needs); false:
+// one set, re-requested at the end of the step -- fits two waves per SIMD at 32 keys per wave, which then hide each other's latency
+template <int D, int NSBW, bool DB = true>
 __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ q,
                                                                 const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
@@ -789,7 +791,7 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
     auto step = [&](auto diag_tag, int t0, v8 (&qa)[2][C::NDC], v8 (&ga)[2][C::NDC], float (&la)[2][4], float (&da)[2][4],
                     v8 (&qn)[2][C::NDC], v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
         constexpr bool DIAG = decltype(diag_tag)::value;
-        request(t0 + 32, qn, gn, ln, dn);
+        if constexpr (DB) request(t0 + 32, qn, gn, ln, dn);
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
@@ -850,18 +852,28 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
                 mma16(dka[db][sbl], qT[db], dsB);
             }
         }
+        if constexpr (!DB) request(t0 + 32, qn, gn, ln, dn);         // qn aliases qa: its last reader has been issued
     };
 
+    typedef std::integral_constant<bool, true> on_diag;
+    typedef std::integral_constant<bool, false> off_diag;
+    if constexpr (!DB) {
+        v8 qA[2][C::NDC], gA[2][C::NDC];
+        float lA[2][4], dA[2][4];
+        request(s0, qA, gA, lA, dA);
+        step(on_diag(), s0, qA, gA, lA, dA, qA, gA, lA, dA);
+        if (s0 + 32 < T_) step(on_diag(), s0 + 32, qA, gA, lA, dA, qA, gA, lA, dA);
+        for (int t0 = s0 + 64; t0 < T_; t0 += 32) step(off_diag(), t0, qA, gA, lA, dA, qA, gA, lA, dA);
+    } else {
     v8 qA[2][C::NDC], gA[2][C::NDC], qB[2][C::NDC], gB[2][C::NDC];
     float lA[2][4], dA[2][4], lB[2][4], dB[2][4];
     request(s0, qA, gA, lA, dA);
-    typedef std::integral_constant<bool, true> on_diag;
-    typedef std::integral_constant<bool, false> off_diag;
     step(on_diag(), s0, qA, gA, lA, dA, qB, gB, lB, dB);                           // rows s0 .. s0+63 can precede keys of this group
     if (s0 + 32 < T_) step(on_diag(), s0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
     for (int t0 = s0 + 64; t0 < T_; t0 += 64) {
         step(off_diag(), t0, qA, gA, lA, dA, qB, gB, lB, dB);
         if (t0 + 32 < T_) step(off_diag(), t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
+    }
     }
 #pragma unroll
     for (int sbl = 0; sbl < NSBW; ++sbl) {
@@ -936,6 +948,17 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
         static const int use64 = [] { const char* e = getenv("MMGL_SELFATTN_DKV64"); return e ? atoi(e) : 1; }();
         if constexpr (sizeof(T) == 2) {
             if (use64) {
+                static const int occ2 = [] { const char* e = getenv("MMGL_SELFATTN_DKV_OCC2"); return e ? atoi(e) : 0; }();
+                if (D <= 64 && occ2) {                       // 32 keys per wave, one register set: two waves per SIMD
+                    typedef XC<bf16, D, 2> C2;
+                    const int nkb32 = cdiv(T_, 32);
+                    const size_t lds32 = sizeof(bf16) * 2 * 32 * (C2::DPAD + 16);
+                    hipLaunchKernelGGL((selfattn_bwd_dkv64_kernel<D, 2, false>), dim3(B * H * nkb32), dim3(64), lds32, st, (const bf16*)dout,
+                                       (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, (bf16*)dk, (bf16*)dv, B, H, T_,
+                                       nkb32, ldq, ldg);
+                    MMGL_CHECK_LAUNCH("selfattn_bwd_dkv32");
+                    return MMGL_OK;
+                }
                 constexpr int NSBW = D <= 64 ? 4 : 2;
                 typedef XC<bf16, D, NSBW> C4;
                 const int nkb64 = cdiv(T_, 16 * NSBW);
