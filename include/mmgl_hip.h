@@ -88,6 +88,18 @@ size_t mmgl_selfattn_bwd_workspace(int B, int H, int T);
 int mmgl_selfattn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse,
                       const uint8_t* key_valid, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
                       int B, int H, int T, int D, int ld_qkv, int ld_dqkv, int dtype, void* stream);
+/* The same attention with P always-visible PREFIX keys in front of the T causal ones: key s is visible to query t iff
+ * s <= t + P (and key_valid[b][s]).
+ * replaces: the self-attention of an OPT layer under peft prefix tuning (reference model/modelling_self_attention.py:88-93,
+ *   PrefixTuningConfig(num_virtual_tokens=20): a learned per-layer key/value prefix that HF concatenates in front of the layer's
+ *   keys and values as past_key_values).
+ *   q, dq [B,T,·] (row strides ld_q / ld_dq), k, v, dk, dv [B,P+T,·] (ld_kv / ld_dkv), key_valid [B,P+T], out, dout [B,T,H*D]
+ *   packed, lse [B,H,T].  P = 0 is mmgl_selfattn_fwd / _bwd.  Workspace: mmgl_selfattn_bwd_workspace(B, H, T). */
+int mmgl_selfattn_prefix_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out, float* lse,
+                             int B, int H, int T, int P, int D, int ld_q, int ld_kv, int dtype, void* stream);
+int mmgl_selfattn_prefix_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse,
+                             const uint8_t* key_valid, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
+                             int B, int H, int T, int P, int D, int ld_q, int ld_kv, int ld_dq, int ld_dkv, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (affine, eps inside the sqrt) over the last dim.

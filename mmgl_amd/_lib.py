@@ -29,6 +29,8 @@ SIGNATURES = {
     "mmgl_selfattn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "mmgl_selfattn_bwd_workspace": (Z, [I, I, I]),
     "mmgl_selfattn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, I, P]),
+    "mmgl_selfattn_prefix_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "mmgl_selfattn_prefix_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, I, I, I, I, P]),
     "mmgl_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, I, P]),
     "mmgl_norm_bwd_workspace": (Z, [I, I]),
     "mmgl_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, I, P]),

@@ -124,7 +124,9 @@ template <typename T, int D>
 __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                            const T* __restrict__ v, const uint8_t* __restrict__ valid,
                                                            T* __restrict__ out, float* __restrict__ lse, int B, int H,
-                                                           int T_, int nqb, int ldq) {
+                                                           int T_, int nqb, int ldq, int P, int ldk) {
+    // P > 0: keys / values carry P always-visible prefix rows in front of the T causal ones (peft prefix tuning: a learned
+    // per-layer key/value prefix); k, v: [B, P + T, ldk], valid: [B, P + T]; key s is visible to query t iff s <= t + P
     typedef SC<T, D> C;
     typedef typename Elem<T>::v8 v8;
     constexpr int TILE = 16 * C::QT, QB = 4 * TILE;
@@ -142,17 +144,18 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = lane & 15, g = lane >> 4;
     const int t0 = qblk * QB + wave * TILE;
-    const int nkt = (min(T_, (qblk + 1) * QB) + KT - 1) / KT;
+    const int Tk = T_ + P;
+    const int nkt = (min(T_, (qblk + 1) * QB) + P + KT - 1) / KT;
 
-    // q, k, v rows are ldq elements apart (ldq = 3 H D when they are column slices of one fused-QKV GEMM output)
-    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T)), rbq = (uint32_t)(ldq * sizeof(T));
+    // q rows are ldq, k / v rows ldk elements apart (3 H D when they are column slices of one fused-QKV GEMM output)
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T)), rbq = (uint32_t)(ldq * sizeof(T)), rbk = (uint32_t)(ldk * sizeof(T));
     const uint32_t slab = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * ldq + h * D, (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T)));
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)b * T_ * HD + h * D, slab);
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
-    const uint32_t slabk = (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T));
-    const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * T_ * ldq + h * D, slabk);
-    const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * T_ * ldq + h * D, slabk);
+    const uint32_t slabk = (uint32_t)(((size_t)(Tk - 1) * ldk + D) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * Tk * ldk + h * D, slabk);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * Tk * ldk + h * D, slabk);
 
     v8 qf[C::QT][C::NDC];
 #pragma unroll
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
     }
 
     TileStage<T, C, false, C::TIMG> stg;
-    stg.loadb(rk, rv, rbq, valid + (size_t)b * T_, 0, T_);
+    stg.loadb(rk, rv, rbk, valid + (size_t)b * Tk, 0, Tk);
     stg.store(Kimg(0), Vimg(0), Vld(0));
     __syncthreads();
     // two LDS tile buffers, ONE barrier per key tile: tile j+1 is written into the other buffer after this wave's MFMAs of
@@ -182,8 +185,8 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
         const T* Kf = Kimg(j & 1);
         const T* Vi = Vimg(j & 1);
         const uint8_t* vld = Vld(j & 1);
-        if (j + 1 < nkt) stg.loadb(rk, rv, rbq, valid + (size_t)b * T_, s0 + KT, T_);
-        if (s0 <= t0 + TILE - 1) {                            // else: tile entirely above this wave's diagonal (wave-uniform)
+        if (j + 1 < nkt) stg.loadb(rk, rv, rbk, valid + (size_t)b * Tk, s0 + KT, Tk);
+        if (s0 <= t0 + P + TILE - 1) {                        // else: tile entirely above this wave's diagonal (wave-uniform)
 
         f32x4 bias[4];
         tile_bias<C>(vld, g, bias);
@@ -199,11 +202,11 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
                 for (int qt = 0; qt < C::QT; ++qt) mma16(sacc[qt][sb], kf, qf[qt][dc]);
             }
         }
-        const bool diag = s0 + KT - 1 > t0;                   // some (key, row) pair of this wave violates s <= t
+        const bool diag = s0 + KT - 1 > t0 + P;               // some (key, row) pair of this wave violates s <= t + P
         v8 pf[C::QT][2];
 #pragma unroll
         for (int qt = 0; qt < C::QT; ++qt) {
-            const int t = t0 + qt * 16 + x;
+            const int t = t0 + qt * 16 + x + P;
             if (diag) {
 #pragma unroll
                 for (int sb = 0; sb < 4; ++sb)
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
                                                               const T* __restrict__ k, const T* __restrict__ v,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               const uint8_t* __restrict__ valid, T* __restrict__ dq, int B, int H,
-                                                              int T_, int nqb, int ldq, int ldg) {
+                                                              int T_, int nqb, int ldq, int ldg, int P, int ldk) {
     typedef XC<T, D, 4, 2> C;
     typedef typename Elem<T>::v8 v8;
     constexpr int TILE = 16 * C::QT, QB = 4 * TILE;
@@ -398,16 +401,17 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = lane & 15, g = lane >> 4;
     const int t0 = qblk * QB + wave * TILE;
-    const int nkt = (min(T_, (qblk + 1) * QB) + KT - 1) / KT;
+    const int Tk = T_ + P;
+    const int nkt = (min(T_, (qblk + 1) * QB) + P + KT - 1) / KT;
 
-    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T)), rbq = (uint32_t)(ldq * sizeof(T)), rbg = (uint32_t)(ldg * sizeof(T));
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T)), rbq = (uint32_t)(ldq * sizeof(T)), rbg = (uint32_t)(ldg * sizeof(T)), rbk = (uint32_t)(ldk * sizeof(T));
     const uint32_t slab = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * ldq + h * D, (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T)));
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(dout + (size_t)b * T_ * HD + h * D, slab);
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(dq + (size_t)b * T_ * ldg + h * D, (uint32_t)(((size_t)(T_ - 1) * ldg + D) * sizeof(T)));
-    const uint32_t slabk = (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T));
-    const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * T_ * ldq + h * D, slabk);
-    const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * T_ * ldq + h * D, slabk);
+    const uint32_t slabk = (uint32_t)(((size_t)(Tk - 1) * ldk + D) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * Tk * ldk + h * D, slabk);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * Tk * ldk + h * D, slabk);
 
     v8 qf[C::QT][C::NDC], gf[C::QT][C::NDC];
     float lse2[C::QT], dlt[C::QT];
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
         for (int db = 0; db < C::NDB; ++db) acc[qt][db] = vzero<f32x4>();
 
     TileStage<T, C, C::TIMG, false> stg;
-    stg.loadb(rk, rv, rbq, valid + (size_t)b * T_, 0, T_);
+    stg.loadb(rk, rv, rbk, valid + (size_t)b * Tk, 0, Tk);
     stg.store(Kimg(0), Vimg(0), Vld(0));
     __syncthreads();
     for (int j = 0; j < nkt; ++j) {                           // double-buffered tiles, one barrier each (see selfattn_fwd_kernel)
@@ -437,12 +441,12 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
         const T* Ki = Kimg(j & 1);
         const T* Vf = Vimg(j & 1);
         const uint8_t* vld = Vld(j & 1);
-        if (j + 1 < nkt) stg.loadb(rk, rv, rbq, valid + (size_t)b * T_, s0 + KT, T_);
-        if (s0 <= t0 + TILE - 1) {
+        if (j + 1 < nkt) stg.loadb(rk, rv, rbk, valid + (size_t)b * Tk, s0 + KT, Tk);
+        if (s0 <= t0 + P + TILE - 1) {
 
         f32x4 bias[4];
         tile_bias<C>(vld, g, bias);
-        const bool diag = s0 + KT - 1 > t0;
+        const bool diag = s0 + KT - 1 > t0 + P;
         v8 dsf[C::QT][2];
         {
             // VALU diet: -delta enters as the C-input of the dP product (acc = dP - delta), the exp argument and dS are packed
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
             }
 #pragma unroll
             for (int qt = 0; qt < C::QT; ++qt) {
-                const int t = t0 + qt * 16 + x;
+                const int t = t0 + qt * 16 + x + P;
                 const f32x4 nl = {-lse2[qt], -lse2[qt], -lse2[qt], -lse2[qt]};
 #pragma unroll
                 for (int sb = 0; sb < 4; ++sb) {
@@ -522,8 +526,10 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
                                                                const T* __restrict__ k, const T* __restrict__ v,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                const uint8_t* __restrict__ valid, T* __restrict__ dk,
-                                                               T* __restrict__ dv, int B, int H, int T_, int nkb, int ldq, int ldg) {
+                                                               T* __restrict__ dv, int B, int H, int T_, int nkb, int ldq, int ldg,
+                                                               int P, int ldk) {
     typedef XC<T, D, 2> C;                         // one wave's key group: 32 keys = 2 blocks
+    const int Tk = T_ + P;                         // keys: P always-visible prefix rows, then the T causal ones
     typedef typename Elem<T>::v8 v8;
     constexpr int LDT = C::DPAD + 16;              // row stride of the wave-private tiles (elements)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -541,19 +547,19 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
     const int b = bh / H, h = bh % H;
     const size_t HD = (size_t)H * D;
     const int s0 = kblk * KT + half * 32;
-    const T* kb = k + ((size_t)b * T_ + kblk * KT) * ldq + h * D;
-    const T* vb = v + ((size_t)b * T_ + kblk * KT) * ldq + h * D;
+    const T* kb = k + ((size_t)b * Tk + kblk * KT) * ldk + h * D;
+    const T* vb = v + ((size_t)b * Tk + kblk * KT) * ldk + h * D;
 
     // stage both halves' K / V row fragments (64 keys): image `half` holds keys [32 half, 32 half + 32)
     for (int hh = 0; hh < 2; ++hh) {
-        stage_row_image<T, C>(Kb + hh * C::ROWIMG, kb + (size_t)hh * 32 * ldq, (size_t)ldq, T_ - (kblk * KT + hh * 32));
-        stage_row_image<T, C>(Vb + hh * C::ROWIMG, vb + (size_t)hh * 32 * ldq, (size_t)ldq, T_ - (kblk * KT + hh * 32));
+        stage_row_image<T, C>(Kb + hh * C::ROWIMG, kb + (size_t)hh * 32 * ldk, (size_t)ldk, Tk - (kblk * KT + hh * 32));
+        stage_row_image<T, C>(Vb + hh * C::ROWIMG, vb + (size_t)hh * 32 * ldk, (size_t)ldk, Tk - (kblk * KT + hh * 32));
     }
     bool vs[2];
 #pragma unroll
     for (int sbl = 0; sbl < 2; ++sbl) {
         const int s = s0 + sbl * 16 + x;
-        vs[sbl] = s < T_ && valid[(size_t)b * T_ + s] != 0;
+        vs[sbl] = s < Tk && valid[(size_t)b * Tk + s] != 0;
     }
     __syncthreads();
     const T* Kh = Kb + half * C::ROWIMG;
@@ -569,7 +575,7 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
     const T* gb = dout + (size_t)b * T_ * HD + h * D;
     const float* lb = lse + (size_t)bh * T_;
     const float* dlb = delta + (size_t)bh * T_;
-    const int tfirst = (s0 / 32) * 32;                          // first 32-row query tile that can see key s0
+    const int tfirst = (max(s0 - P, 0) / 32) * 32;              // first 32-row query tile that can see key s0 (visible iff s <= t + P)
 
     v8 qn[2][C::NDC], gn[2][C::NDC];                         // next tile's fragments, in flight during this tile's MFMAs
 #pragma unroll
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
                 *(v8*)(Qt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = qa[tb][dc];
                 *(v8*)(Gt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = ga[tb][dc];
             }
-        const bool diag = t0 < s0 + 31;                         // some (row, key) pair with key > row
+        const bool diag = t0 + P < s0 + 31;                     // some (row, key) pair with key > row + P
         f32x4 pr[2][2], dsr[2][2];
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int t = t0 + tb * 16 + g * 4 + r;
-                    const bool ok = tv[r] && vs[sbl] && (!diag || s <= t);
+                    const bool ok = tv[r] && vs[sbl] && (!diag || s <= t + P);
                     const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sa[r], LOG2E, -lt[r])) : 0.f;
                     pr[tb][sbl][r] = p;
                     dsr[tb][sbl][r] = p * (pa[r] - dt[r]);
@@ -687,8 +693,8 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
 #pragma unroll
         for (int sbl = 0; sbl < 2; ++sbl) {
             const int s = s0 + sbl * 16 + x;
-            if (s < T_) {
-                const size_t off = ((size_t)b * T_ + s) * ldg + h * D + g * 4;
+            if (s < Tk) {
+                const size_t off = ((size_t)b * Tk + s) * ldg + h * D + g * 4;
 #pragma unroll
                 for (int db = 0; db < C::NDB; ++db) {
                     f32x4 a = dka[db][sbl], c = dva[db][sbl];
@@ -722,8 +728,10 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
                                                                 const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 const uint8_t* __restrict__ valid, bf16* __restrict__ dk,
-                                                                bf16* __restrict__ dv, int B, int H, int T_, int nkb, int ldq, int ldg) {
+                                                                bf16* __restrict__ dv, int B, int H, int T_, int nkb, int ldq, int ldg,
+                                                                int P, int ldk) {
     typedef bf16 T;
+    const int Tk = T_ + P;                         // keys: P always-visible prefix rows, then the T causal ones
     typedef XC<T, D, NSBW> C;
     constexpr int KW = 16 * NSBW;                  // keys per wave
     typedef bf16x8 v8;
@@ -739,11 +747,12 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
     const int b = bh / H, h = bh % H;
     const size_t HD = (size_t)H * D;
     const int s0 = kblk * KW;
-    const uint32_t rbq = (uint32_t)(ldq * sizeof(T)), rbo = (uint32_t)(HD * sizeof(T));
+    const uint32_t rbq = (uint32_t)(ldq * sizeof(T)), rbo = (uint32_t)(HD * sizeof(T)), rbk = (uint32_t)(ldk * sizeof(T));
     const uint32_t slabq = (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T)), slabo = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
+    const uint32_t slabk = (uint32_t)(((size_t)(Tk - 1) * ldk + D) * sizeof(T));
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * ldq + h * D, slabq);
-    const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * T_ * ldq + h * D, slabq);
-    const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * T_ * ldq + h * D, slabq);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * Tk * ldk + h * D, slabk);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * Tk * ldk + h * D, slabk);
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(dout + (size_t)b * T_ * HD + h * D, slabo);
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(delta + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
@@ -753,11 +762,11 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
 #pragma unroll
     for (int sbl = 0; sbl < NSBW; ++sbl) {
         const int s = s0 + sbl * 16 + x;
-        kbias[sbl] = (s < T_ && valid[(size_t)b * T_ + min(s, T_ - 1)] != 0) ? 0.f : -INFINITY;
+        kbias[sbl] = (s < Tk && valid[(size_t)b * Tk + min(s, Tk - 1)] != 0) ? 0.f : -INFINITY;
 #pragma unroll
         for (int dc = 0; dc < C::NDC; ++dc) {
-            kf[sbl][dc] = buf_load8<T>(rk, row_off<T, C>(s, rbq, dc * 32 + g * 8));
-            vf[sbl][dc] = buf_load8<T>(rv, row_off<T, C>(s, rbq, dc * 32 + g * 8));
+            kf[sbl][dc] = buf_load8<T>(rk, row_off<T, C>(s, rbk, dc * 32 + g * 8));
+            vf[sbl][dc] = buf_load8<T>(rv, row_off<T, C>(s, rbk, dc * 32 + g * 8));
         }
     }
     f32x4 dva[C::NDB][NSBW], dka[C::NDB][NSBW];
@@ -839,7 +848,7 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
                 f32x4 e = sa * LOG2E;
                 if constexpr (DIAG) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) e[r] = (s <= t0 + tb * 16 + g * 4 + r) ? e[r] : -INFINITY;
+                    for (int r = 0; r < 4; ++r) e[r] = (s <= t0 + tb * 16 + g * 4 + r + P) ? e[r] : -INFINITY;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pr[tb][r] = __builtin_amdgcn_exp2f(e[r]);
@@ -857,29 +866,37 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
 
     typedef std::integral_constant<bool, true> on_diag;
     typedef std::integral_constant<bool, false> off_diag;
+    // query rows that can see this key group start at s0 - P (key s is visible to row t iff s <= t + P); a step is diagonal
+    // (needs the causal select) while some of its rows precede some key of the group
+    const int tstart = max(s0 - P, 0) & ~31;
+    const int tdiag = s0 + KW - 1 - P;                               // steps with t0 < tdiag are diagonal
     if constexpr (!DB) {
         v8 qA[2][C::NDC], gA[2][C::NDC];
         float lA[2][4], dA[2][4];
-        request(s0, qA, gA, lA, dA);
-        step(on_diag(), s0, qA, gA, lA, dA, qA, gA, lA, dA);
-        if (s0 + 32 < T_) step(on_diag(), s0 + 32, qA, gA, lA, dA, qA, gA, lA, dA);
-        for (int t0 = s0 + 64; t0 < T_; t0 += 32) step(off_diag(), t0, qA, gA, lA, dA, qA, gA, lA, dA);
+        request(tstart, qA, gA, lA, dA);
+        for (int t0 = tstart; t0 < T_; t0 += 32) {
+            if (t0 < tdiag) step(on_diag(), t0, qA, gA, lA, dA, qA, gA, lA, dA);
+            else step(off_diag(), t0, qA, gA, lA, dA, qA, gA, lA, dA);
+        }
     } else {
-    v8 qA[2][C::NDC], gA[2][C::NDC], qB[2][C::NDC], gB[2][C::NDC];
-    float lA[2][4], dA[2][4], lB[2][4], dB[2][4];
-    request(s0, qA, gA, lA, dA);
-    step(on_diag(), s0, qA, gA, lA, dA, qB, gB, lB, dB);                           // rows s0 .. s0+63 can precede keys of this group
-    if (s0 + 32 < T_) step(on_diag(), s0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
-    for (int t0 = s0 + 64; t0 < T_; t0 += 64) {
-        step(off_diag(), t0, qA, gA, lA, dA, qB, gB, lB, dB);
-        if (t0 + 32 < T_) step(off_diag(), t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
-    }
+        v8 qA[2][C::NDC], gA[2][C::NDC], qB[2][C::NDC], gB[2][C::NDC];
+        float lA[2][4], dA[2][4], lB[2][4], dB[2][4];
+        request(tstart, qA, gA, lA, dA);
+        int t0 = tstart;
+        for (; t0 < T_ && t0 < tdiag; t0 += 64) {                    // diagonal steps (two without a prefix, up to three with one)
+            step(on_diag(), t0, qA, gA, lA, dA, qB, gB, lB, dB);
+            if (t0 + 32 < T_) step(on_diag(), t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
+        }
+        for (; t0 < T_; t0 += 64) {
+            step(off_diag(), t0, qA, gA, lA, dA, qB, gB, lB, dB);
+            if (t0 + 32 < T_) step(off_diag(), t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
+        }
     }
 #pragma unroll
     for (int sbl = 0; sbl < NSBW; ++sbl) {
         const int s = s0 + sbl * 16 + x;
-        if (s < T_) {
-            const size_t off = ((size_t)b * T_ + s) * ldg + h * D + g * 4;
+        if (s < Tk) {
+            const size_t off = ((size_t)b * Tk + s) * ldg + h * D + g * 4;
 #pragma unroll
             for (int db = 0; db < C::NDB; ++db) {
                 store4<T>(dk + off + db * 16, dka[db][sbl]);
@@ -901,7 +918,7 @@ template <typename K> int set_lds_sa(K kern, size_t bytes) {
 
 template <typename T, int D>
 int sa_fwd(const void* q, const void* k, const void* v, const uint8_t* valid, void* out, float* lse, int B, int H, int T_,
-           int ldq, hipStream_t st) {
+           int ldq, int P, int ldk, hipStream_t st) {
     typedef SC<T, D> C;
     const int QB = 4 * 16 * C::QT, nqb = cdiv(T_, QB);
     const size_t lds = 2 * (sizeof(T) * (C::ROWIMG + (C::TIMG ? C::RMIMG : C::ROWIMG)) + KT);
@@ -909,14 +926,15 @@ int sa_fwd(const void* q, const void* k, const void* v, const uint8_t* valid, vo
     int rc = set_lds_sa(kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(B * H * nqb), dim3(256), lds, st, (const T*)q, (const T*)k, (const T*)v, valid, (T*)out, lse, B, H,
-                       T_, nqb, ldq);
+                       T_, nqb, ldq, P, ldk);
     MMGL_CHECK_LAUNCH("selfattn_fwd");
     return MMGL_OK;
 }
 
 template <typename T, int D>
 int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, const uint8_t* valid,
-           void* dq, void* dk, void* dv, float* delta, int B, int H, int T_, int ldq, int ldg, hipStream_t st) {
+           void* dq, void* dk, void* dv, float* delta, int B, int H, int T_, int ldq, int ldg, int P, int ldk, int ldgk, hipStream_t st) {
+    // ldq / ldg: row strides of q / dq; ldk / ldgk: of k, v / dk, dv ([B, P + T] rows); P prefix keys (0 = plain causal attention)
     {
         const size_t total = (size_t)B * T_ * H * (D / 8);
         int blocks = (int)((total + 255) / 256);
@@ -932,13 +950,13 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
         int rc = set_lds_sa(kern, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(kern, dim3(B * H * nqb), dim3(256), lds, st, (const T*)dout, (const T*)q, (const T*)k, (const T*)v, lse,
-                           delta, valid, (T*)dq, B, H, T_, nqb, ldq, ldg);
+                           delta, valid, (T*)dq, B, H, T_, nqb, ldq, ldg, P, ldk);
         MMGL_CHECK_LAUNCH("selfattn_bwd_dq");
     }
     {
         typedef XC<T, D, 2> C;
         constexpr int LDT = C::DPAD + 16;
-        const int nkb = cdiv(T_, KT);
+        const int nkb = cdiv(T_ + P, KT);
         const size_t red = sizeof(float) * 2 * 2 * (C::NDB * 2 * 64 * 4);
         auto lds_for = [&](int par) {
             size_t tiles = sizeof(T) * (2 * par) * 2 * 32 * LDT;
@@ -951,21 +969,21 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
                 static const int occ2 = [] { const char* e = getenv("MMGL_SELFATTN_DKV_OCC2"); return e ? atoi(e) : 0; }();
                 if (D <= 64 && occ2) {                       // 32 keys per wave, one register set: two waves per SIMD
                     typedef XC<bf16, D, 2> C2;
-                    const int nkb32 = cdiv(T_, 32);
+                    const int nkb32 = cdiv(T_ + P, 32);
                     const size_t lds32 = sizeof(bf16) * 2 * 32 * (C2::DPAD + 16);
                     hipLaunchKernelGGL((selfattn_bwd_dkv64_kernel<D, 2, false>), dim3(B * H * nkb32), dim3(64), lds32, st, (const bf16*)dout,
                                        (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, (bf16*)dk, (bf16*)dv, B, H, T_,
-                                       nkb32, ldq, ldg);
+                                       nkb32, ldq, ldgk, P, ldk);
                     MMGL_CHECK_LAUNCH("selfattn_bwd_dkv32");
                     return MMGL_OK;
                 }
                 constexpr int NSBW = D <= 64 ? 4 : 2;
                 typedef XC<bf16, D, NSBW> C4;
-                const int nkb64 = cdiv(T_, 16 * NSBW);
+                const int nkb64 = cdiv(T_ + P, 16 * NSBW);
                 const size_t lds64 = sizeof(bf16) * 2 * 32 * (C4::DPAD + 16);
                 hipLaunchKernelGGL((selfattn_bwd_dkv64_kernel<D, NSBW>), dim3(B * H * nkb64), dim3(64), lds64, st, (const bf16*)dout,
                                    (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, (bf16*)dk, (bf16*)dv, B, H, T_,
-                                   nkb64, ldq, ldg);
+                                   nkb64, ldq, ldgk, P, ldk);
                 MMGL_CHECK_LAUNCH("selfattn_bwd_dkv64");
                 return MMGL_OK;
             }
@@ -975,13 +993,13 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
             int rc = set_lds_sa(kern, lds_for(2));
             if (rc) return rc;
             hipLaunchKernelGGL(kern, dim3(B * H * nkb), dim3(256), lds_for(2), st, (const T*)dout, (const T*)q, (const T*)k, (const T*)v,
-                               lse, delta, valid, (T*)dk, (T*)dv, B, H, T_, nkb, ldq, ldg);
+                               lse, delta, valid, (T*)dk, (T*)dv, B, H, T_, nkb, ldq, ldgk, P, ldk);
         } else {
             auto kern = selfattn_bwd_dkv_kernel<T, D, 1>;
             int rc = set_lds_sa(kern, lds_for(1));
             if (rc) return rc;
             hipLaunchKernelGGL(kern, dim3(B * H * nkb), dim3(128), lds_for(1), st, (const T*)dout, (const T*)q, (const T*)k, (const T*)v,
-                               lse, delta, valid, (T*)dk, (T*)dv, B, H, T_, nkb, ldq, ldg);
+                               lse, delta, valid, (T*)dk, (T*)dv, B, H, T_, nkb, ldq, ldgk, P, ldk);
         }
         MMGL_CHECK_LAUNCH("selfattn_bwd_dkv");
     }
@@ -1027,15 +1045,20 @@ static int sa_ld(const char* who, int& ld, int H, int D) {
     return MMGL_OK;
 }
 
+extern "C" int mmgl_selfattn_prefix_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out, float* lse,
+                                        int B, int H, int T, int P, int D, int ld_q, int ld_kv, int dtype, void* stream) {
+    int rc = sa_check("mmgl_selfattn_prefix_fwd", B, H, T, D, dtype);
+    if (rc) return rc;
+    MMGL_CHECK_ARG(q && k && v && key_valid && out && lse && P >= 0, "mmgl_selfattn_prefix_fwd: bad arguments");
+    if ((rc = sa_ld("mmgl_selfattn_prefix_fwd", ld_q, H, D)) || (rc = sa_ld("mmgl_selfattn_prefix_fwd", ld_kv, H, D))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMGL_BF16) { SA_DISPATCH(sa_fwd, bf16, q, k, v, key_valid, out, lse, B, H, T, ld_q, P, ld_kv, st) }
+    SA_DISPATCH(sa_fwd, float, q, k, v, key_valid, out, lse, B, H, T, ld_q, P, ld_kv, st)
+}
+
 extern "C" int mmgl_selfattn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out, float* lse,
                                  int B, int H, int T, int D, int ld_qkv, int dtype, void* stream) {
-    int rc = sa_check("mmgl_selfattn_fwd", B, H, T, D, dtype);
-    if (rc) return rc;
-    MMGL_CHECK_ARG(q && k && v && key_valid && out && lse, "mmgl_selfattn_fwd: null pointer");
-    if ((rc = sa_ld("mmgl_selfattn_fwd", ld_qkv, H, D))) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == MMGL_BF16) { SA_DISPATCH(sa_fwd, bf16, q, k, v, key_valid, out, lse, B, H, T, ld_qkv, st) }
-    SA_DISPATCH(sa_fwd, float, q, k, v, key_valid, out, lse, B, H, T, ld_qkv, st)
+    return mmgl_selfattn_prefix_fwd(q, k, v, key_valid, out, lse, B, H, T, 0, D, ld_qkv, ld_qkv, dtype, stream);
 }
 
 extern "C" size_t mmgl_selfattn_bwd_workspace(int B, int H, int T) {
@@ -1043,18 +1066,26 @@ extern "C" size_t mmgl_selfattn_bwd_workspace(int B, int H, int T) {
     return align_up((size_t)B * H * T * sizeof(float), 256);
 }
 
+extern "C" int mmgl_selfattn_prefix_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse,
+                                        const uint8_t* key_valid, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
+                                        int B, int H, int T, int P, int D, int ld_q, int ld_kv, int ld_dq, int ld_dkv, int dtype, void* stream) {
+    int rc = sa_check("mmgl_selfattn_prefix_bwd", B, H, T, D, dtype);
+    if (rc) return rc;
+    if ((rc = sa_ld("mmgl_selfattn_prefix_bwd", ld_q, H, D)) || (rc = sa_ld("mmgl_selfattn_prefix_bwd", ld_kv, H, D)) ||
+        (rc = sa_ld("mmgl_selfattn_prefix_bwd", ld_dq, H, D)) || (rc = sa_ld("mmgl_selfattn_prefix_bwd", ld_dkv, H, D))) return rc;
+    MMGL_CHECK_ARG(dout && q && k && v && out && lse && key_valid && dq && dk && dv && workspace && P >= 0, "mmgl_selfattn_prefix_bwd: bad arguments");
+    MMGL_CHECK_ARG(workspace_bytes >= mmgl_selfattn_bwd_workspace(B, H, T), "mmgl_selfattn_prefix_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* delta = (float*)workspace;
+    if (dtype == MMGL_BF16) { SA_DISPATCH(sa_bwd, bf16, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_q, ld_dq, P, ld_kv, ld_dkv, st) }
+    SA_DISPATCH(sa_bwd, float, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_q, ld_dq, P, ld_kv, ld_dkv, st)
+}
+
 extern "C" int mmgl_selfattn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse,
                                  const uint8_t* key_valid, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
                                  int B, int H, int T, int D, int ld_qkv, int ld_dqkv, int dtype, void* stream) {
-    int rc = sa_check("mmgl_selfattn_bwd", B, H, T, D, dtype);
-    if (rc) return rc;
-    if ((rc = sa_ld("mmgl_selfattn_bwd", ld_qkv, H, D)) || (rc = sa_ld("mmgl_selfattn_bwd", ld_dqkv, H, D))) return rc;
-    MMGL_CHECK_ARG(dout && q && k && v && out && lse && key_valid && dq && dk && dv && workspace, "mmgl_selfattn_bwd: null pointer");
-    MMGL_CHECK_ARG(workspace_bytes >= mmgl_selfattn_bwd_workspace(B, H, T), "mmgl_selfattn_bwd: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    float* delta = (float*)workspace;
-    if (dtype == MMGL_BF16) { SA_DISPATCH(sa_bwd, bf16, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_qkv, ld_dqkv, st) }
-    SA_DISPATCH(sa_bwd, float, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_qkv, ld_dqkv, st)
+    return mmgl_selfattn_prefix_bwd(dout, q, k, v, out, lse, key_valid, dq, dk, dv, workspace, workspace_bytes, B, H, T, 0, D, ld_qkv,
+                                    ld_qkv, ld_dqkv, ld_dqkv, dtype, stream);
 }
 
 extern "C" int mmgl_encattn_fwd(const void* q, const void* k, const void* v, const int32_t* cu_seqlens, void* out, int nseq,

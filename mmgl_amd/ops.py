@@ -158,6 +158,54 @@ def selfattn_core(q, k, v, key_valid, num_heads):
     return _SelfAttnCore.apply(q, k, v, key_valid.contiguous(), num_heads)
 
 
+class _SelfAttnPrefix(torch.autograd.Function):
+    """Causal self-attention with P always-visible prefix keys in front of the T causal ones (mmgl_selfattn_prefix_fwd/_bwd)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_valid, num_heads, P):
+        require_cuda(q, k, v, key_valid)
+        B, T, d = q.shape
+        D = d // num_heads
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out = torch.empty_like(q)
+        lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=q.device)
+        _lib.call("mmgl_selfattn_prefix_fwd", dict(flops=2.0 * B * T * (T + 2 * P) * d, bytes=4.0 * B * T * d * q.element_size()),
+                  ptr(q), ptr(k), ptr(v), ptr(key_valid), ptr(out), ptr(lse), B, num_heads, T, P, D, 0, 0, dtype_code(q), stream_ptr())
+        ctx.save_for_backward(q, k, v, key_valid, out, lse)
+        ctx.num_heads, ctx.P = num_heads, P
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, key_valid, out, lse = ctx.saved_tensors
+        H, P = ctx.num_heads, ctx.P
+        B, T, d = q.shape
+        D = d // H
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        nbytes = lib().mmgl_selfattn_bwd_workspace(B, H, T)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        _lib.call("mmgl_selfattn_prefix_bwd", dict(flops=5.0 * B * T * (T + 2 * P) * d, bytes=8.0 * B * T * d * q.element_size()),
+                  ptr(dout), ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(key_valid), ptr(dq), ptr(dk), ptr(dv), ptr(ws), nbytes,
+                  B, H, T, P, D, 0, 0, 0, 0, dtype_code(q), stream_ptr())
+        return dq, dk, dv, None, None, None
+
+
+def selfattn_core_prefix(q, k, v, key_valid, num_heads, prefix_len):
+    """softmax(mask(q k^T)) v where k, v [B, P+T, d] carry P = prefix_len always-visible rows in front of the T causal ones:
+    mask = (s <= t + P) & key_valid[b, s]; q [B, T, d] is already scaled.  The attention of an OPT layer under peft prefix tuning
+    (reference model/modelling_self_attention.py:88-93: HF prepends the learned per-layer key/value prefix as past_key_values)."""
+    if q.dim() != 3 or k.shape != v.shape or k.shape[0] != q.shape[0] or k.shape[2] != q.shape[2] or k.shape[1] != q.shape[1] + prefix_len:
+        raise ValueError(f"selfattn_core_prefix: incompatible shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)} for a prefix of {prefix_len}")
+    if q.shape[2] % num_heads:
+        raise ValueError(f"embed_dim must be divisible by num_heads (got `embed_dim`: {q.shape[2]} and `num_heads`: {num_heads}).")
+    if key_valid.shape != k.shape[:2]:
+        raise ValueError(f"Attention mask should be of size {tuple(k.shape[:2])}, but is {tuple(key_valid.shape)}")
+    if key_valid.dtype != torch.uint8:
+        key_valid = key_valid.to(torch.uint8)
+    return _SelfAttnPrefix.apply(q, k, v, key_valid.contiguous(), num_heads, int(prefix_len))
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 

@@ -99,3 +99,46 @@ def test_selfattn_fused_qkv_is_bitwise_the_separate_path(B, H, T, D, dtype):
     gq, gk, gv = torch.autograd.grad((out_s * w).sum(), (q, k, v))
     assert torch.equal(out_f, out_s)
     assert torch.equal(g_f, torch.cat([gq, gk, gv], -1))
+
+
+PREFIX_CASES = [  # B, H, T, P, D
+    (2, 2, 24, 4, 16),       # tiny
+    (2, 3, 100, 20, 32),     # peft's 20 virtual tokens, ragged T
+    (3, 4, 640, 20, 64),     # OPT shape: P = 20 is no multiple of a tile (three diagonal steps in the dK/dV kernel)
+    (1, 2, 300, 64, 128),    # a whole key tile of prefix, head dim 128
+]
+
+
+@pytest.mark.parametrize("B,H,T,P,D", PREFIX_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_selfattn_prefix_fwd_bwd_vs_oracle(B, H, T, P, D, dtype):
+    """Prefix tuning's attention: P learned keys / values in front of the layer's own, visible to every query; the T causal keys
+    keep their padding mask.  Oracle: the reference's additive-mask attention core over the concatenated keys."""
+    from mmgl_amd import ops
+    from oracle import lm_ref
+    gen = torch.Generator().manual_seed(B * 1000 + T + P)
+    d = H * D
+    q = torch.randn(B, T, d, generator=gen) * (D ** -0.5) * 2
+    k = torch.randn(B, P + T, d, generator=gen)
+    v = torch.randn(B, P + T, d, generator=gen)
+    w = torch.randn(B, T, d, generator=gen)
+    am = torch.ones(B, P + T, dtype=torch.long)
+    am[0, P + T // 2: P + T - T // 5] = 0
+    if B > 1:
+        am[1, P + T // 3:] = 0
+    qd, kd, vd = (t.to(dtype).cuda().requires_grad_() for t in (q, k, v))
+    out = ops.selfattn_core_prefix(qd, kd, vd, am.cuda(), H, P)
+    (out * w.to(dtype).cuda()).sum().backward()
+    # additive mask [B, 1, T, P + T]: key s allowed for query t iff s <= t + P and am[b, s]
+    s_idx, t_idx = torch.arange(P + T)[None, :], torch.arange(T)[:, None]
+    allowed = (s_idx <= t_idx + P)[None] & am.bool()[:, None, :]
+    mask = torch.where(allowed, 0.0, torch.finfo(torch.float32).min)[:, None]
+    qr, kr, vr = (t.detach().float().cpu().requires_grad_() for t in (qd, kd, vd))
+    ro = lm_ref.attention_core(qr, kr, vr, mask, H)
+    (ro * w.to(dtype).float()).sum().backward()
+    tol = 1e-3 if dtype == torch.float32 else 2e-2
+    assert torch.isfinite(out).all()
+    assert_close(out.float(), ro.detach(), tol, "out")
+    assert_close(qd.grad.float(), qr.grad, tol, "dq")
+    assert_close(kd.grad.float(), kr.grad, tol, "dk")
+    assert_close(vd.grad.float(), vr.grad, tol, "dv")
