@@ -190,7 +190,7 @@ class MPTAttention(nn.Module):
         return cache[1]
 
     # -- causal self-attention of the (frozen) OPT layers: HIP flash kernels, no [B,1,T,T] mask, no [B,H,T,T] scores
-    def _forward_self(self, hidden_states, attention_mask, layer_head_mask, output_attentions):
+    def _forward_self(self, hidden_states, attention_mask, layer_head_mask, output_attentions, past_key_value=None):
         H = self.num_heads
         if attention_mask is None or attention_mask.dim() != 2:
             raise ValueError("self-attention takes the [bsz, seq_len] key mask (causality is implied); additive 4-D masks are "
@@ -198,7 +198,22 @@ class MPTAttention(nn.Module):
         if layer_head_mask is not None or output_attentions or (self.training and self.dropout > 0):
             raise ValueError("layer_head_mask / output_attentions / attention dropout are not available on the fused self-attention kernels")
         fused = self._frozen_qkv()
-        if fused is not None:                # frozen layer: one QKV GEMM forward, one dgrad GEMM backward, no gradient adds
+        if past_key_value is not None:
+            # prefix tuning (peft hands the learned per-layer key/value prefix to HF as past_key_values): P extra keys / values in
+            # front of the layer's own, visible to every query; attention_mask is the [bsz, P + seq_len] key mask
+            kp, vp = past_key_value
+            B, T, d = hidden_states.shape
+            P = kp.shape[-2]
+            if fused is not None:
+                qkv = ops.frozen_linear(hidden_states, *fused)
+                q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+            else:
+                q = _lin(self.q_proj, hidden_states) * self.scaling
+                k, v = _lin(self.k_proj, hidden_states), _lin(self.v_proj, hidden_states)
+            k = torch.cat([kp.to(k.dtype).expand(B, P, d), k], dim=1)
+            v = torch.cat([vp.to(v.dtype).expand(B, P, d), v], dim=1)
+            o = ops.selfattn_core_prefix(q, k, v, attention_mask, H, P)
+        elif fused is not None:              # frozen layer: one QKV GEMM forward, one dgrad GEMM backward, no gradient adds
             o = ops.selfattn_core_fused(ops.frozen_linear(hidden_states, *fused), attention_mask, H)
         else:
             if type(self.q_proj) is nn.Linear and self.q_proj.weight.requires_grad:
@@ -213,7 +228,7 @@ class MPTAttention(nn.Module):
         """Input shape: Batch x Time x Channel.  Returns (attn_output, attn_weights-or-None, None)."""
         if self.cross_attention:
             return self._forward_cross(hidden_states, neighbor_embeds, neighbor_attention_mask, layer_head_mask, output_attentions)
-        return self._forward_self(hidden_states, attention_mask, layer_head_mask, output_attentions)
+        return self._forward_self(hidden_states, attention_mask, layer_head_mask, output_attentions, past_key_value)
 
 
 _FUSE_ADD_LN = os.environ.get("MMGL_FUSE_ADD_LN", "1") != "0"     # A/B switch for the fused residual + LayerNorm pairs
@@ -283,7 +298,7 @@ class MPTDecoderLayer(nn.Module):
             h = self._ln(self.final_layer_norm, h)
         return h, attn_w
 
-    def _forward_self(self, h, attention_mask, layer_head_mask, output_attentions, defer_residual=False):
+    def _forward_self(self, h, attention_mask, layer_head_mask, output_attentions, defer_residual=False, past_key_value=None):
         """OPT layer (frozen in every peft mode of the reference, :731-737): GEMMs, attention (ops.selfattn_core*), LayerNorm and
         dropout + residual all run on this repo's HIP kernels.  Every `residual + dropout(branch)` is folded into the LayerNorm that
         follows it (ops.add_layer_norm_pair: one forward and one backward kernel per pair); the layer's last add can be
@@ -301,7 +316,7 @@ class MPTDecoderLayer(nn.Module):
             x = self._ln(ln1, h) if pre else h
         residual = h
         a, attn_w, _ = self.self_attn(x, attention_mask=attention_mask, layer_head_mask=layer_head_mask,
-                                      output_attentions=output_attentions)
+                                      output_attentions=output_attentions, past_key_value=past_key_value)
         if fuse and pre:
             h, x = pair(a, residual, ln2)
         elif fuse:
@@ -337,7 +352,7 @@ class MPTDecoderLayer(nn.Module):
             h, attn_w = self._forward_cross(_materialize(hidden_states), neighbor_embeds, neighbor_attention_mask, layer_head_mask,
                                             output_attentions)
         else:
-            h, attn_w = self._forward_self(hidden_states, attention_mask, layer_head_mask, output_attentions, defer_residual)
+            h, attn_w = self._forward_self(hidden_states, attention_mask, layer_head_mask, output_attentions, defer_residual, past_key_value)
         outputs = (h,)
         if output_attentions:
             outputs += (attn_w,)
@@ -422,8 +437,24 @@ class MPTDecoder(MPTPreTrainedModel):
         output_attentions = bool(output_attentions)
         output_hidden_states = bool(output_hidden_states)
         return_dict = True if return_dict is None else return_dict
-        if past_key_values is not None or use_cache:
+        if use_cache:
             raise ValueError("KV-cache decoding is not implemented (the reference's cross-attention ignores the cache, :275)")
+        # past_key_values: a FIXED per-layer key/value prefix (peft prefix tuning, reference model/modelling_self_attention.py:88-93),
+        # either peft's prefix-encoder table [P, 2 * n_layers * d] (layer i: keys = columns [2i d, (2i+1) d), values the next d)
+        # or a sequence of (key [P or B x P, d], value) pairs, one per layer
+        prefix_len = 0
+        if past_key_values is not None:
+            if torch.is_tensor(past_key_values):
+                d_model = self.config.hidden_size
+                if past_key_values.dim() != 2 or past_key_values.shape[1] != 2 * len(self.layers) * d_model:
+                    raise ValueError(f"past_key_values: expected a prefix table [P, 2 * {len(self.layers)} * {d_model}], got {tuple(past_key_values.shape)}")
+                past_key_values = [(past_key_values[:, 2 * i * d_model:(2 * i + 1) * d_model],
+                                    past_key_values[:, (2 * i + 1) * d_model:(2 * i + 2) * d_model]) for i in range(len(self.layers))]
+            if len(past_key_values) != len(self.layers):
+                raise ValueError(f"past_key_values: {len(past_key_values)} entries for {len(self.layers)} layers")
+            prefix_len = past_key_values[0][0].shape[-2]
+            if self.cross_attention:
+                raise ValueError("a key/value prefix is only defined for the plain (self-attention) decoder")
         if input_ids is not None and inputs_embeds is not None:
             raise ValueError("You cannot specify both decoder_input_ids and decoder_inputs_embeds at the same time")
         elif input_ids is not None:
@@ -437,10 +468,12 @@ class MPTDecoder(MPTPreTrainedModel):
             inputs_embeds = self.embed_tokens(input_ids)
         batch_size, seq_length = input_shape
         if attention_mask is None:
-            attention_mask = torch.ones(batch_size, seq_length, device=inputs_embeds.device)
-        elif attention_mask.shape[1] != seq_length:
+            attention_mask = torch.ones(batch_size, seq_length + prefix_len, device=inputs_embeds.device)
+        elif attention_mask.shape[1] == seq_length and prefix_len:
+            attention_mask = torch.cat([attention_mask.new_ones(batch_size, prefix_len), attention_mask], dim=1)   # prefix keys are always visible
+        elif attention_mask.shape[1] != seq_length + prefix_len:
             raise ValueError(f"The provided attention mask has length {attention_mask.shape[1]}, but its length should be "
-                             f"{seq_length} (sum of the lengths of current and past inputs)")
+                             f"{seq_length + prefix_len} (sum of the lengths of current and past inputs)")
         if output_attentions or head_mask is not None or (self.training and self.config.attention_dropout > 0):
             raise ValueError("output_attentions / head_mask / attention_dropout need materialised attention weights, which the fused "
                              "self-attention kernels never form")
@@ -458,7 +491,7 @@ class MPTDecoder(MPTPreTrainedModel):
         if neighbor_embeds is not None and neighbor_embeds.dtype != inputs_embeds.dtype:
             neighbor_embeds = neighbor_embeds.to(inputs_embeds.dtype)
 
-        pos_embeds = self.embed_positions(attention_mask, 0)
+        pos_embeds = self.embed_positions(attention_mask, prefix_len)      # positions count the prefix (HF: past_key_values_length)
         if self.project_in is not None:
             inputs_embeds = _lin(self.project_in, inputs_embeds)
         hidden_states = inputs_embeds + pos_embeds
@@ -478,7 +511,8 @@ class MPTDecoder(MPTPreTrainedModel):
                     continue
             lhm = head_mask[idx] if head_mask is not None else None
             layer_outputs = decoder_layer(hidden_states, attention_mask=causal_attention_mask, layer_head_mask=lhm,
-                                          output_attentions=output_attentions, defer_residual=defer)
+                                          output_attentions=output_attentions, defer_residual=defer,
+                                          past_key_value=None if past_key_values is None else past_key_values[idx])
             if self.cross_attention and neighbor_embeds is not None and (idx + 1) % self.neighbor_layer_wise == 0:
                 hidden_states = _materialize(layer_outputs[0])
                 neighbor_idx = (idx + 1) // self.neighbor_layer_wise - 1

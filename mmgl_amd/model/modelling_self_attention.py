@@ -10,8 +10,9 @@ layers, identical state-dict keys) on the HIP kernels.  What else this build own
     trainable (peft's modules_to_save=["lm_head"], reference :80-87).  The reference's target_modules
     ["query","value"] are BERT names that match nothing in OPT/T5; the evident intent
     (q_proj/v_proj for OPT, q/v for T5) is implemented.  Parity vs peft is UNPINNED.
-  * prompt tuning (20 virtual tokens, random init) as a learned prefix of input embeddings; prefix tuning is
-    implemented as the same learned input prefix (peft's per-layer key/value prefix needs HF cache internals).
+  * prompt tuning (20 virtual tokens, random init) as a learned prefix of input embeddings; prefix tuning of the decoder-only
+    OPT as peft's per-layer key/value prefix (a [20, 2 * n_layers * d] table fed to every layer's attention as fixed
+    past_key_values: ops.selfattn_core_prefix); for T5 (stock HF model, CPU plumbing) it stays the learned input prefix.
   * the neighbor encoders, interleave scatter (HIP), Laplacian-PE linear and GCN PE exactly as :282-332, with the
     reference's "session" typos read as "section" (SURVEY.md 3.4).
 """
@@ -117,6 +118,7 @@ class SelfAttentionModel(nn.Module):
             raise ValueError(f"SelfAttentionModel does not support {name}.")
 
         self.prompt_embeddings = None
+        self.prefix_encoder = None
         if args.peft_type == "none":
             pass
         elif args.peft_type == "lora":
@@ -125,7 +127,14 @@ class SelfAttentionModel(nn.Module):
             for p in model.parameters():
                 p.requires_grad = False
             d = model.get_input_embeddings().embedding_dim
-            self.prompt_embeddings = nn.Embedding(NUM_VIRTUAL_TOKENS, d)
+            if args.peft_type == "prefix" and "opt" in name:
+                # peft's PrefixEncoder without projection: one table [P, 2 * n_layers * d]; layer i takes columns
+                # [2i d, (2i+1) d) as its key prefix and the next d as its value prefix (heads x head_dim inside d), handed
+                # to the decoder as a fixed per-layer past_key_values (mmgl_selfattn_prefix_fwd/_bwd)
+                n_layers = model.config.num_hidden_layers
+                self.prefix_encoder = nn.Embedding(NUM_VIRTUAL_TOKENS, 2 * n_layers * model.config.hidden_size)
+            else:
+                self.prompt_embeddings = nn.Embedding(NUM_VIRTUAL_TOKENS, d)
         else:
             raise ValueError(f"SelfAttentionModel does not support {args.peft_type}.")
         self.lm = model
@@ -238,9 +247,13 @@ class SelfAttentionModel(nn.Module):
             attention_mask = torch.cat([attention_mask.new_ones(B, NUM_VIRTUAL_TOKENS), attention_mask], dim=1)
             if self.decoder_only and labels is not None:
                 labels = torch.cat([labels.new_full((B, NUM_VIRTUAL_TOKENS), -100), labels], dim=1)
+        kw = {}
+        if self.prefix_encoder is not None:
+            # labels and logits keep the sequence length: the prefix lives in the attention of every layer, not in the sequence
+            kw["past_key_values"] = self.prefix_encoder.weight.to(self.input_embeddings.weight.dtype)
         if input_embs is not None:
-            return self.lm(inputs_embeds=input_embs, attention_mask=attention_mask, labels=labels)
-        return self.lm(input_ids=input_ids, attention_mask=attention_mask, labels=labels)
+            return self.lm(inputs_embeds=input_embs, attention_mask=attention_mask, labels=labels, **kw)
+        return self.lm(input_ids=input_ids, attention_mask=attention_mask, labels=labels, **kw)
 
     def forward(self, input_ids, attention_mask, labels, images=None, image_positions=None, neighbor_input_ids=None,
                 neighbor_attention_mask=None, neighbor_pos_ids=None, text_locations=None, neighbor_images=None,

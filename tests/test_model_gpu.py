@@ -205,3 +205,46 @@ def test_initialize_lm_from_pretrained_round_trip(tmp_path):
         out = w(input_ids=ids.cuda(), attention_mask=am.cuda(), labels=ids.cuda())
     assert_close(out.logits, ref.logits, TOL, "logits vs HF OPT loaded from the same checkpoint")
     assert_close(out.loss, ref.loss, TOL, "loss")
+
+
+@pytest.mark.parametrize("pre_ln", [True, False])
+def test_prefix_tuning_equals_hf_opt_with_past_key_values(pre_ln):
+    """peft prefix tuning = a learned, fixed past_key_values for every layer of the frozen HF OPT (reference
+    model/modelling_self_attention.py:88-93).  The fork takes peft's prefix table [P, 2 * n_layers * d] and runs the prefix inside
+    its attention kernels; logits, loss and the gradient of the table must equal HF OPT fed the same prefix as a cache."""
+    from transformers import DynamicCache, OPTForCausalLM
+    from mmgl_amd.model.modelling_cross_attention import MPTConfig, MPTForCausalLM, copy_opt_weights
+    torch.manual_seed(5)
+    oc = tiny_opt_config(pre_ln=pre_ln, dropout=0.0)
+    hf = OPTForCausalLM(oc).eval()
+    lm = MPTForCausalLM(MPTConfig(mpt_args(neighbor_mode="raw", peft_type="none"), oc))
+    copy_opt_weights(hf, lm)
+    lm = lm.cuda().eval()
+    for p in lm.parameters():
+        p.requires_grad = False
+    B, T, P = 3, 24, 5
+    L, d, H = oc.num_hidden_layers, oc.hidden_size, oc.num_attention_heads
+    ids = torch.randint(3, oc.vocab_size, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, 17:] = 0
+    am[2, 9:] = 0
+    ids = torch.where(am.bool(), ids, torch.full_like(ids, oc.pad_token_id))
+    labels = torch.where(am.bool(), ids, torch.full_like(ids, -100))
+    table = torch.randn(P, 2 * L * d)
+
+    t_ref = table.clone().requires_grad_()
+    cache = DynamicCache()
+    for i in range(L):
+        k = t_ref[:, 2 * i * d:(2 * i + 1) * d].view(P, H, d // H).permute(1, 0, 2)[None].expand(B, H, P, d // H)
+        v = t_ref[:, (2 * i + 1) * d:(2 * i + 2) * d].view(P, H, d // H).permute(1, 0, 2)[None].expand(B, H, P, d // H)
+        cache.update(k, v, i)
+    ro = hf(input_ids=ids, attention_mask=torch.cat([torch.ones(B, P, dtype=torch.long), am], 1), past_key_values=cache, labels=labels)
+    ro.loss.backward()
+
+    t_dev = table.clone().cuda().requires_grad_()
+    o = lm(input_ids=ids.cuda(), attention_mask=am.cuda(), labels=labels.cuda(), past_key_values=t_dev, return_logits=True)
+    o.loss.backward()
+    valid = am.bool()
+    assert_close(o.logits[valid.cuda()], ro.logits.detach()[valid], TOL, "logits vs HF OPT + past_key_values")
+    assert_close(o.loss, ro.loss.detach(), TOL, "loss")
+    assert_close(t_dev.grad, t_ref.grad, 5e-3, "d loss / d prefix table")

@@ -68,6 +68,39 @@ def test_lora_injection_trains_only_adapters_and_head():
             assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, n
 
 
+def test_prefix_tuning_wrapper_trains_only_the_prefix_table():
+    """peft_type="prefix" on the decoder-only OPT: the only trainable LM-side parameter is peft's prefix table
+    [20, 2 * n_layers * d]; logits keep the sequence length (the prefix lives inside the attention of every layer, not in the
+    sequence); a zero-gradient-free backward reaches the table through all layers; prompt tuning stays an input prefix."""
+    from mmgl_amd.model import SelfAttentionModel
+    from mmgl_amd.model.modelling_self_attention import NUM_VIRTUAL_TOKENS
+    torch.manual_seed(0)
+    oc = tiny_opt_config(dropout=0.0)
+    w = SelfAttentionModel(_sa_args(peft_type="prefix", context="all"), None, lm_config=oc, text_config=tiny_roberta_config(),
+                           visual_config=tiny_clip_vision_config()).cuda().eval()
+    assert w.prompt_embeddings is None
+    assert tuple(w.prefix_encoder.weight.shape) == (NUM_VIRTUAL_TOKENS, 2 * oc.num_hidden_layers * oc.hidden_size)
+    assert not any(p.requires_grad for p in w.lm.parameters())
+    fx = Fixture("g9_selfattn_none.npz")
+    b = {k: v.cuda() for k, v in fx.inp.items()}
+    out = w(**b)
+    assert out.logits.shape == fx.out["logits"].shape          # no virtual tokens in the sequence
+    out.loss.backward()
+    g = w.prefix_encoder.weight.grad
+    assert g is not None and torch.isfinite(g).all()
+    per_layer = g.view(NUM_VIRTUAL_TOKENS, oc.num_hidden_layers, 2, oc.hidden_size).abs().amax(dim=(0, 3))
+    assert (per_layer > 0).all(), "every layer's key and value prefix must receive a gradient"
+    # the prefix changes the output (it is not a no-op) ...
+    with torch.no_grad():
+        w.prefix_encoder.weight.mul_(0.0)
+        zeroed = w(**b)
+    assert (zeroed.logits - out.logits).abs().max() > 1e-4
+    # ... and prompt tuning remains the input-embedding prefix (sequence grows by the virtual tokens)
+    wp = SelfAttentionModel(_sa_args(peft_type="prompt", context="all"), None, lm_config=oc, text_config=tiny_roberta_config(),
+                            visual_config=tiny_clip_vision_config()).cuda().eval()
+    assert wp.prefix_encoder is None and wp(**b).logits.shape[1] == fx.out["logits"].shape[1] + NUM_VIRTUAL_TOKENS
+
+
 def test_trainer_flamingo_synthetic_one_gpu(tmp_path):
     """run_generation on cuda:0: mpt-tiny, context=all, neighbor_mode=embedding, flamingo; loss goes down, checkpoint
     round-trips, a resumed model reproduces the validation metrics."""
