@@ -55,7 +55,8 @@ struct P8Args {
     int nsplit;            // K splits per output tile (1 = none): work item = (tile, split), fp32 partial tiles into `part`
     float* part;           // [nsplit][M][N] fp32 (ACT = 5 kernels)
     int stagger;           // start delay per CU group in units of 4096 clocks (0 = none)
-    long long* trace;      // timing experiments only (P8_TRACE builds): [8 waves][64] clock stamps of workgroup 0
+    long long* trace;      // timing experiments only (P8_TRACE builds): [8 waves][64] clock stamps of workgroup trace_wg
+    int trace_wg;
 };
 
 // ACT is a compile-time family: 0 = none, 1 = ReLU, 2 gelu (erf), 3 quick_gelu, 4 gelu (tanh)
@@ -197,7 +198,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
 #if P8_TRACE
     int tr_n = 0;
     auto stamp = [&](int it_) __attribute__((always_inline)) {
-        if (a.trace && blockIdx.x == 0 && it_ >= 2 && tr_n < 64) {
+        if (a.trace && (int)blockIdx.x == a.trace_wg && it_ >= 2 && tr_n < 64) {
             const long long t = __builtin_readcyclecounter();
             if (lane == 0) a.trace[wave * 64 + tr_n] = t;      // a plain store: perturbs vmcnt a little, same for every variant compared
             ++tr_n;
@@ -644,8 +645,10 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
     // a quarter of a tile time, ~11 clocks per unit of K (256 x 256 x K MACs at the sustained rate), when there are >= 3 rounds
     a.stagger = (stag_on && a.total >= 3 * grid) ? (K * 11 * stag_on + 2048) / 4096 : 0;
     a.trace = nullptr;
+    a.trace_wg = 0;
 #if P8_TRACE
     if (const char* e = getenv("MMGL_P8_TRACE")) a.trace = (long long*)strtoull(e, nullptr, 0);
+    if (const char* e = getenv("MMGL_P8_TRACE_WG")) a.trace_wg = atoi(e);
 #endif
     const bool zr = resid || zmask;
 #define P8_LAUNCH(A, Z) hipLaunchKernelGGL((gemm8p_kernel<A, Z>), dim3(grid), dim3(512), P8_LDS_TOTAL, st, a)
