@@ -1113,6 +1113,8 @@ extern "C" int mmgl_linear_wgrad(const void* dy, const void* y, const void* x, v
 }
 
 // One call for the whole backward of a linear: dyp once, then dx / dW / dbias as requested (any of them may be NULL).
+extern "C" int mmgl_gemm_nt_fast(int M, int N, int K, int ldx, int ldw, int ldy, int dtype);
+
 template <typename T>
 int linear_bwd(const T* dy, const T* y, const T* x, const T* W, T* dx, T* dW, T* dbias, char* ws, int M, int N, int K, int act,
                float scale, int accumulate, hipStream_t st, bool mask_dx = false) {
@@ -1131,9 +1133,10 @@ int linear_bwd(const T* dy, const T* y, const T* x, const T* W, T* dx, T* dW, T*
         }
         int rc = MMGL_OK;
         if (dx) {
-            if (tune_gemm_big() && big_tile_shape(M, K, N)) {
-                // large shapes: dx = dyp . (W^T)^T on the 256x256 NT kernel; transposing the [N,K] weight costs a few
-                // percent of the GEMM (it is M/256 times smaller than the activations)
+            if (tune_gemm_big() && (big_tile_shape(M, K, N) || (N % 128 == 0 && mmgl_gemm_nt_fast(M, K, N, N, N, K, MMGL_BF16)))) {
+                // (sending every M >= 1024 dgrad through W^T and the 128x128 NT kernel was tried: no gain in the batch-4 step)
+                // shapes the persistent kernel takes (a chip of 256x256 tiles, or K-split work items at the reference's small
+                // batch): dx = dyp . (W^T)^T as an NT GEMM; transposing the [N,K] weight costs a few percent of the GEMM
                 T* Wt = (T*)(ws + bf16_wt_offset(M, N, act));
                 rc = launch_transpose<T>(W, nullptr, Wt, nullptr, N, K, 1.f, 0, st);
                 bool masked = false;
