@@ -38,7 +38,7 @@ typedef unsigned p8_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int P8_UNIT = 16384;      // bytes per staged unit
 constexpr int P8_LDS = 8 * P8_UNIT;
-constexpr int P8_LDS_TOTAL = P8_LDS + 8 * 1024;      // + one 1 KiB bias line per wave
+constexpr int P8_LDS_TOTAL = P8_LDS + 16 * 1024;     // + two 1 KiB bias lines per wave (tile parity)
 
 struct P8Args {
     const bf16* X;
@@ -87,6 +87,9 @@ __device__ __forceinline__ int p8_lane() {
     return l;
 }
 
+#ifndef P8_SPREAD
+#define P8_SPREAD 0                  // 1: epilogue of tile i quadrant by quadrant inside the first four phases of tile i+1 (measured 7 % slower)
+#endif
 #ifndef P8_RELAX
 #define P8_RELAX 0                   // 1: relaxed vmcnt in a tile's first five phases (peeled first K-tile pair); measured neutral, kept for experiments
 #endif
@@ -234,10 +237,11 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     // each, the others point outside the descriptor and deposit zeros): no register holds them across the tile.  The descriptor
     // covers bias[0..N) (empty without a bias): columns past N and the no-bias case read as zero, branch-free.
     const __amdgpu_buffer_rsrc_t dBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 2 : 0, 0x00020000);
-    auto fetch_bias = [&](int nt0) __attribute__((always_inline)) {
+    // two lines per wave, by tile parity: with the spread epilogue a tile's line is read during the NEXT tile's first phases
+    auto fetch_bias = [&](int nt0, int par) __attribute__((always_inline)) {
         const int ln = p8_lane();
         const unsigned off = ln < 8 ? (unsigned)((nt0 + wc * 64 + ln * 8) * 2) : 0xffffffffu;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(dBias, (lds_void*)(smem + P8_LDS + wave * 1024), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dBias, (lds_void*)(smem + P8_LDS + (par & 1) * 8192 + wave * 1024), 16, off, 0, 0, 0);
     };
     auto y_desc = [&](const bf16* base, int mt0) {
         long long rem = (long long)(a.M - mt0) * a.ldy * 2;
@@ -249,7 +253,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     // are whole-quadrant loops of packed fp32 ops behind uniform branches, and plain ReLU is one packed integer max on the
     // converted bf16 pairs (a negative bf16 is a negative int16).  ZR kernels request the 16 zmask (else residual) vectors of
     // the tile up front: one exposed memory latency per tile instead of one per quadrant.
-    auto epilogue = [&]() __attribute__((always_inline)) {
+    auto epilogue_q = [&](int m0, int n0, int par, int q_lo, int q_hi) __attribute__((always_inline)) {
         if constexpr (ACT == 5) {
             // K-split work item: the raw fp32 accumulators of this split go to part[sp][m][n]; bias / activation / masks are
             // applied by p8_splitk_finish_kernel when it folds the splits
@@ -295,9 +299,10 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (q < q_lo || q >= q_hi) continue;
             const int J0 = (q == 0 || q == 1) ? 0 : 4, T0 = (q == 0 || q == 3) ? 0 : 2;
             if (has_bias) {
-                const bf16x8 br = *(const bf16x8*)(smem + P8_LDS + wave * 1024 + ((ln >> 4) + 2 * T0) * 16);     // columns 32 (T0 / 2) + 8 g ..
+                const bf16x8 br = *(const bf16x8*)(smem + P8_LDS + (par & 1) * 8192 + wave * 1024 + ((ln >> 4) + 2 * T0) * 16);     // columns 32 (T0 / 2) + 8 g ..
                 const f32x4 b0 = {(float)br[0], (float)br[1], (float)br[2], (float)br[3]}, b1 = {(float)br[4], (float)br[5], (float)br[6], (float)br[7]};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { acc[T0][J0 + j] += b0; acc[T0 + 1][J0 + j] += b1; }
@@ -364,6 +369,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
             for (int j = 0; j < 4; ++j) { acc[T0][J0 + j] = vzero<f32x4>(); acc[T0 + 1][J0 + j] = vzero<f32x4>(); }
         }
     };
+    auto epilogue = [&]() __attribute__((always_inline)) { epilogue_q(m0, n0, it, 0, 4); };
 
     // ---- stagger.  Every CU runs equal tiles in lockstep, so all 256 of them would reach their epilogues together and push
     // 32 MiB of output at the memory system at once; with one in-order vmcnt per wave the next tile's LDS-DMA waits sit behind
@@ -390,7 +396,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         for (int j = 0; j < 8; ++j) acc[t][j] = vzero<f32x4>();
     // two W fragment sets that swap roles every K tile: even K tiles keep Wa in fwA and Wb in fwB, odd ones Wa in fwB, Wb in fwA
     bf16x8 fx[2][4], fwA[2][2], fwB[2][2];
-    fetch_bias(n0);                      // the lane's 16 bias values of the first tile
+    fetch_bias(n0, 0);                   // the lane's 16 bias values of the first tile
 #if P8_RELAX
     P8_VMCNT(0);                         // the whole prologue has landed: the relaxed counts of a tile's first phases assume that
 #else                                    // everything issued before the tile is complete, or older than the epilogue's stores
@@ -437,34 +443,49 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     // of them, so the count that keeps "5 younger units in flight" grows by 17: with vmcnt(10) the first phase of every tile
     // would wait for the stores to be acknowledged (a 128 KiB burst per CU: 3-10k clocks) instead of running under them.
 #define P8_PHASE_T(READ, TY, SLOT, DK, FX, FW, J0, T0) P8_PHASE_M(READ, TY, SLOT, DK, FX, FW, J0, T0, P8_MM, 27)
+    // Spread epilogue (kernels without zmask / residual loads).  A quadrant of accumulators is not touched again until the
+    // phase of the NEXT tile that restarts it, so tile i's epilogue runs quadrant by quadrant at the head of the first four
+    // phases of tile i+1 -- in this wave group's memory cluster, beside the partner group's MFMA cluster -- instead of as one
+    // block between the tiles during which the matrix pipes idle and 128 KiB of stores hit the CU's store path at once.  Four
+    // stores per wave and phase join the in-order VMEM queue ahead of that phase's LDS-DMA, so the counted waits of the tile's
+    // first eight phases grow by the stores still younger than the unit each one needs (14, 18, 22, 26, 26, 22, 18, 14 instead of
+    // 10).  The first tile of a workgroup has nothing to store (plain loop: the relaxed counts would not cover its own units) and
+    // the last one ends with the block epilogue.
+    // MEASURED: correct, and 7 % SLOWER over the step's shapes (6.67 -> 7.14 ms for the nine of tools/probes/gemm_variants.py): a
+    // wave cannot issue its next store while the CU's store path is backed up (128 KiB take ~8k clocks to leave the CU, four
+    // phases are 2.2k), so the stall moves into the memory cluster, which the partner group waits for at every barrier.  The
+    // block epilogue stalls only once.  Left here, off, as the record of the experiment.
+    constexpr bool SPREAD = P8_SPREAD && !ZR && ACT != 5;
+#define P8_PHASE_S(Q, WAITN, READ, TY, SLOT, DK, FX, FW, J0, T0)                                  \
+    do {                                                                                         \
+        epilogue_q(pm0, pn0, it - 1, (Q), (Q) + 1);                                              \
+        P8_PHASE_M(READ, TY, SLOT, DK, FX, FW, J0, T0, P8_MM, WAITN);                            \
+    } while (0)
+    int pm0 = 0, pn0 = 0;
     for (;;) {
-        // the lane's 16 bias values for this tile: fetched now, consumed by the epilogue a whole tile later (the wait for them
-        // is a counted vmcnt behind many younger loads, never a drain of the LDS-DMA stream)
         P8_STAMP(it);
-#if P8_RELAX
-        {
+        int kt_begin = 0;
+        if (SPREAD && it > 0) {
             const int kt = 0;
-            P8_PHASE_T(rdX(fx, 0), 2, 6, 1, fx, fwA, 0, 0);
+            P8_PHASE_S(0, 14, rdX(fx, 0), 2, 6, 1, fx, fwA, 0, 0);
             P8_STAMP(it);
-            P8_PHASE_T(rdW(fwB, 1), 3, 7, 2, fx, fwB, 0, 2);
+            P8_PHASE_S(1, 18, rdW(fwB, 1), 3, 7, 2, fx, fwB, 0, 2);
             P8_STAMP(it);
-            P8_PHASE_T(rdX(fx, 2), 0, 0, 2, fx, fwB, 4, 2);
+            P8_PHASE_S(2, 22, rdX(fx, 2), 0, 0, 2, fx, fwB, 4, 2);
             P8_STAMP(it);
-            P8_PHASE_T(rdW(fwB, 3), 1, 1, 2, fx, fwA, 4, 0);
+            P8_PHASE_S(3, 26, rdW(fwB, 3), 1, 1, 2, fx, fwA, 4, 0);
             P8_STAMP(it);
-            P8_PHASE_T(rdX(fx, 4), 2, 2, 2, fx, fwB, 0, 0);
+            P8_PHASE_M(rdX(fx, 4), 2, 2, 2, fx, fwB, 0, 0, P8_MM, 26);
             P8_STAMP(it);
-            P8_PHASE(rdW(fwA, 5), 3, 3, 3, fx, fwA, 0, 2);
+            P8_PHASE_M(rdW(fwA, 5), 3, 3, 3, fx, fwA, 0, 2, P8_MM, 22);
             P8_STAMP(it);
-            P8_PHASE(rdX(fx, 6), 0, 4, 3, fx, fwA, 4, 2);
+            P8_PHASE_M(rdX(fx, 6), 0, 4, 3, fx, fwA, 4, 2, P8_MM, 18);
             P8_STAMP(it);
-            P8_PHASE(rdW(fwA, 7), 1, 5, 3, fx, fwB, 4, 0);
+            P8_PHASE_M(rdW(fwA, 7), 1, 5, 3, fx, fwB, 4, 0, P8_MM, 14);
             P8_STAMP(it);
+            kt_begin = 2;
         }
-        for (int kt = 2; kt < nk; kt += 2) {
-#else
-        for (int kt = 0; kt < nk; kt += 2) {
-#endif
+        for (int kt = kt_begin; kt < nk; kt += 2) {
             P8_PHASE(rdX(fx, 0), 2, 6, 1, fx, fwA, 0, 0);
             if (kt < 4) P8_STAMP(it);
             P8_PHASE(rdW(fwB, 1), 3, 7, 2, fx, fwB, 0, 2);
@@ -483,24 +504,32 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
             if (kt < 4) P8_STAMP(it);
         }
         P8_STAMP(it);
-        // epilogue of tile (m0, n0), beside the partner wave's MFMAs (waves 0-3 and 4-7 reach it half a phase apart)
-        // The two wave groups reach this point half a phase apart, and whichever runs its epilogue holds the other at its next
-        // barrier: left alone, the two epilogues (and tile switches) run one after the other (~13k clocks per tile in the clock
-        // stamps).  One extra barrier each re-aligns them: waves 0-3 take theirs before the epilogue (it pairs with the barrier
-        // inside waves 4-7's last MFMA cluster), waves 4-7 after the tile switch (it pairs with the first barrier of waves 0-3's
-        // next phase) -- both groups then do their epilogues between the same two barriers, side by side.
+        if (SPREAD) {
+            if (!have_next) {                                // last tile of this workgroup: block epilogue
+                epilogue();
+                break;
+            }
+        } else {
+            // The two wave groups reach this point half a phase apart, and whichever runs its epilogue holds the other at its
+            // next barrier: left alone, the two epilogues (and tile switches) run one after the other (~13k clocks per tile in
+            // the clock stamps).  One extra barrier each re-aligns them: waves 0-3 take theirs before the epilogue (it pairs with
+            // the barrier inside waves 4-7's last MFMA cluster), waves 4-7 after the tile switch (it pairs with the first barrier
+            // of waves 0-3's next phase) -- both groups then do their epilogues between the same two barriers, side by side.
 #if P8_REALIGN
-        if (!wr) P8_BARRIER();
+            if (!wr) P8_BARRIER();
 #endif
 #if !(P8_ABLATE & 1)
-        epilogue();
+            epilogue();
 #endif
-        P8_STAMP(it);
+            P8_STAMP(it);
 #if P8_REALIGN
-        if (!have_next) { if (wr) P8_BARRIER(); break; }
+            if (!have_next) { if (wr) P8_BARRIER(); break; }
 #else
-        if (!have_next) break;
+            if (!have_next) break;
 #endif
+        }
+        pm0 = m0;
+        pn0 = n0;
         ++it;
         m0 = m1;
         n0 = n1;
@@ -511,9 +540,9 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         have_next = tile_origin(it + 1, m1, n1, k1, nk1, sp1);
         dXn = mk_desc(a.X, m1, a.M, a.ldx, k1, have_next);
         dWn = mk_desc(a.W, n1, a.N, a.ldw, k1, have_next);
-        fetch_bias(n0);                  // the next tile's bias values: consumed by its epilogue a whole tile from now
+        fetch_bias(n0, it);              // the next tile's bias values: consumed by its epilogue a whole tile from now
 #if P8_REALIGN
-        if (wr) P8_BARRIER();
+        if (!SPREAD && wr) P8_BARRIER();
 #endif
     }
     P8_VMCNT(0);                         // no LDS-DMA may outlive the workgroup
