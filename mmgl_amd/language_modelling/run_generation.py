@@ -257,6 +257,13 @@ def _host_meta(model, batch):
     return {}
 
 
+def _is_opt_self_attention(model):
+    """SelfAttentionModel over this build's OPT fork: its forward takes logits_slice too (a frozen head -- prefix / prompt tuning --
+    then never materialises the full logits in a training step)."""
+    from ..model.modelling_self_attention import SelfAttentionModel
+    return isinstance(model, SelfAttentionModel) and hasattr(model.lm, "model") and hasattr(model.lm.model, "decoder")
+
+
 def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, run=None):
     """One epoch (reference :430-524).  `engine` = DataParallelEngine (replaces DDP + optimizer)."""
     from . import utils
@@ -278,9 +285,10 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
     for i, batch in enumerate(train_loader):
         data_time.update(time.time() - end)
         extra = _host_meta(model, batch)               # read off the batch while it is still in host memory
-        sliced = bool(extra) and args.decoder_only
+        sliced = args.decoder_only and (bool(extra) or _is_opt_self_attention(model))
         if sliced:                                     # the running summary loss below reads positions L_in .. T-2 only: the training
-            extra["logits_slice"] = slice(args.max_input_length, -1)       # step then never builds the [B, T, V] logits
+            # step then never builds the [B, T, V] logits (explicit stop: SelfAttentionModel appends neighbor tokens after position T-1)
+            extra["logits_slice"] = slice(args.max_input_length, batch["input_ids"].shape[1] - 1)
         batch = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
         boundary = ((i + 1) % accum == 0) or (i == args.steps_per_epoch - 1)
         engine.sync = boundary                         # gradients cross xGMI once per optimizer step

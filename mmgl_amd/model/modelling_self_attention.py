@@ -238,6 +238,15 @@ class SelfAttentionModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------ LM call
     def _run_lm(self, input_embs=None, input_ids=None, attention_mask=None, labels=None):
+        kw = {}
+        opts = getattr(self, "_logit_opts", None)
+        if opts and hasattr(self.lm, "model") and "t5" not in self.args.model_name_or_path:
+            # the OPT fork: a training step with a frozen head never builds [B, T, V] logits unless asked (lm_head_loss_and_logits)
+            rl, sl = opts
+            if sl is not None and self.prompt_embeddings is not None:               # virtual tokens sit in front of the sequence
+                shift = lambda v: v + NUM_VIRTUAL_TOKENS if (v is not None and v >= 0) else v
+                sl = slice(shift(sl.start if sl.start is not None else 0), shift(sl.stop), sl.step)
+            kw.update(return_logits=rl, logits_slice=sl)
         if self.prompt_embeddings is not None:
             if input_embs is None:
                 input_embs = self.input_embeddings(input_ids)
@@ -247,7 +256,6 @@ class SelfAttentionModel(nn.Module):
             attention_mask = torch.cat([attention_mask.new_ones(B, NUM_VIRTUAL_TOKENS), attention_mask], dim=1)
             if self.decoder_only and labels is not None:
                 labels = torch.cat([labels.new_full((B, NUM_VIRTUAL_TOKENS), -100), labels], dim=1)
-        kw = {}
         if self.prefix_encoder is not None:
             # labels and logits keep the sequence length: the prefix lives in the attention of every layer, not in the sequence
             kw["past_key_values"] = self.prefix_encoder.weight.to(self.input_embeddings.weight.dtype)
@@ -257,7 +265,10 @@ class SelfAttentionModel(nn.Module):
 
     def forward(self, input_ids, attention_mask, labels, images=None, image_positions=None, neighbor_input_ids=None,
                 neighbor_attention_mask=None, neighbor_pos_ids=None, text_locations=None, neighbor_images=None,
-                neighbor_images_pos_ids=None, image_locations=None, lpe=None, graph=None, host_meta=None):
+                neighbor_images_pos_ids=None, image_locations=None, lpe=None, graph=None, host_meta=None, return_logits=None,
+                logits_slice=None):
+        # return_logits / logits_slice: see modelling_cross_attention.lm_head_loss_and_logits (decoder-only OPT fork only)
+        self._logit_opts = (return_logits, logits_slice) if (return_logits is not None or logits_slice is not None) else None
         # host_meta (optional, see modelling_cross_attention.host_metadata): accepted for a uniform trainer call; this wrapper
         # encodes every neighbor slot (the concatenated sequence keeps padded slots as masked keys), so it has no use for it
         if self.neighbor_mode == "raw" and self.context in ("section_only", "text_only"):
