@@ -248,3 +248,67 @@ def test_prefix_tuning_equals_hf_opt_with_past_key_values(pre_ln):
     assert_close(o.logits[valid.cuda()], ro.logits.detach()[valid], TOL, "logits vs HF OPT + past_key_values")
     assert_close(o.loss, ro.loss.detach(), TOL, "loss")
     assert_close(t_dev.grad, t_ref.grad, 5e-3, "d loss / d prefix table")
+
+
+def test_full_size_opt_1_3b_step_loss_matches_cpu_oracle():
+    """BASELINE.json config 3 at its real dimensions (OPT-1.3B, d = 2048, 24 + 4 layers, 11 + 5 neighbors, T = 640, roberta-base +
+    CLIP ViT-B/16 encoders; random init): the bf16 HIP forward of one synthetic sample against the fp32 CPU oracle of the same
+    weights and batch -- every kernel of the path at full size in one number.  Tolerance: bf16 rounding through 28 layers."""
+    import bench
+    from oracle import lm_ref, wrapper_ref
+    from mmgl_amd.model import CrossAttentionModel
+    cfg = bench.CONFIGS["opt-1.3b"]
+    lm_cfg, txt_cfg, vis_cfg = bench.hf_configs(cfg)
+    torch.manual_seed(1234)
+    with torch.device("cpu"):
+        model = CrossAttentionModel(bench.make_args(cfg), tokenizer=None, lm_config=lm_cfg, text_config=txt_cfg, visual_config=vis_cfg)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.endswith("gating1") or n_.endswith("gating2"):
+                p.fill_(0.5)
+    model.eval()
+    batch, _ = bench.synthetic_batch(2, cfg, seed=99, device=torch.device("cpu"))
+    b = {k: v[:1] for k, v in batch.items() if k != "host_meta"}
+    # oracle (fp32, CPU)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    sd = {k: v.detach().float() for k, v in model.state_dict().items()}
+    gates = [k for k, p in model.named_parameters() if p.requires_grad and (k.endswith("gating1") or k.endswith("gating2"))]
+    probes = gates + ["text_embeddings.bias", "visual_embeddings.bias"]
+    for k in probes:
+        sd[k].requires_grad_()
+    ocfg = lm_ref.LMConfig(vocab_size=lm_cfg.vocab_size, hidden_size=lm_cfg.hidden_size, num_attention_heads=lm_cfg.num_attention_heads,
+                           ffn_dim=lm_cfg.ffn_dim, num_hidden_layers=lm_cfg.num_hidden_layers,
+                           word_embed_proj_dim=lm_cfg.word_embed_proj_dim, neighbor_layer_wise=cfg["wise"])
+    with torch.no_grad():
+        L = b["neighbor_input_ids"].shape[-1]
+        tl = model.text_model(input_ids=b["neighbor_input_ids"].reshape(-1, L), attention_mask=b["neighbor_attention_mask"].reshape(-1, L)).last_hidden_state
+        vp = model.visual_model(b["neighbor_images"].reshape(-1, 3, 224, 224)).pooler_output
+    _, ref_loss = wrapper_ref.cross_attention_model_forward(sd, ocfg, b, tl, vp, "all", 4)
+    ref_loss.backward()
+    # HIP path, fp32 first (same arithmetic as the oracle up to summation order): tight check of the gradients
+    dev = model.cuda()
+    out32 = dev(**{k: v.cuda() for k, v in b.items()})
+    out32.loss.backward()
+    assert abs(float(out32.loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss)), (float(out32.loss), float(ref_loss))
+    p32 = dict(dev.named_parameters())
+    for k in gates:
+        g, r = float(p32[k].grad), float(sd[k].grad)
+        print(f"   fp32 d loss / d {k}: {g:+.5e} vs {r:+.5e}")
+        assert abs(g - r) <= 1e-2 * abs(r) + 2e-6, (k, g, r)
+    for k in ("text_embeddings.bias", "visual_embeddings.bias"):
+        assert_close(p32[k].grad.float().cpu(), sd[k].grad, 1e-2, f"fp32 d {k}")
+    dev.zero_grad(set_to_none=True)
+    # HIP path (bf16): forward and backward through all 28 layers
+    dev = model.to(torch.bfloat16).cuda()
+    out = dev(**{k: v.cuda() for k, v in b.items()})
+    out.loss.backward()
+    print(f"full-size config 3, one sample: HIP bf16 loss {float(out.loss):.5f} vs CPU oracle fp32 {float(ref_loss):.5f}")
+    assert torch.isfinite(out.loss)
+    assert abs(float(out.loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
+    params = dict(dev.named_parameters())
+    for k in gates:                                        # scalar gates: the gradient through everything above them
+        g, r = float(params[k].grad), float(sd[k].grad)
+        print(f"   d loss / d {k}: {g:+.5e} vs {r:+.5e}")
+        assert abs(g - r) <= 0.35 * abs(r) + 2e-4, (k, g, r)      # a sum of 1.3 M signed bf16 products: loose by nature (fp32 above is tight)
+    for k in ("text_embeddings.bias", "visual_embeddings.bias"):
+        assert_close(params[k].grad.float().cpu(), sd[k].grad, 0.1, f"d {k}")
