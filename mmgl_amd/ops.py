@@ -739,6 +739,9 @@ def gemm_nt(x2, w, bias=None, residual=None, zmask=None, act=0, out_scale=1.0, K
     y = torch.empty(M, N, dtype=x2.dtype, device=x2.device) if out is None else out
     if M == 0:
         return y
+    for name, t in (("zmask", zmask), ("residual", residual)):
+        if t is not None and (t.stride(1) != 1 or t.stride(0) != y.stride(0)):
+            raise ValueError(f"gemm_nt: {name} must share the output's row stride ({t.stride(0)} vs {y.stride(0)})")
     _lib.call("mmgl_gemm_nt", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x2.element_size(),
                                    tag=f"{M}x{N}x{K}" + ("+b" if bias is not None else "") + ("+z" if zmask is not None else "")
                                        + ("+r" if residual is not None else "") + (f"+a{act}" if act else "")),
@@ -774,6 +777,9 @@ def frozen_dgrad(g, weight, zmask=None, out=None):
     kk = wt.shape[1]
     if kk != N and not lib().mmgl_gemm_nt_fast(g.shape[0], K, kk, g.stride(0), kk, K, dtype_code(g)):
         wt, kk = wt[:, :N].contiguous(), N                # shape not on the fast path: dense operands
+    if out is None and zmask is not None and zmask.stride(0) != zmask.shape[1]:
+        # the mask (a ReLU output kept with a padded row pitch, see _ffn_pitch) shares the output's row stride in the epilogue
+        out = torch.empty(zmask.shape[0], zmask.stride(0), dtype=g.dtype, device=g.device)[:, :zmask.shape[1]]
     if out is not None and kk % (8 if g.dtype == torch.bfloat16 else 4) == 0 and K % 8 == 0:
         return gemm_nt(g, wt, zmask=zmask, K=kk, out=out)
     dx = _gemm_nt_padded(g, wt, zmask=zmask, K=kk)
@@ -783,23 +789,52 @@ def frozen_dgrad(g, weight, zmask=None, out=None):
     return dx
 
 
+_FFN_PITCH = os.environ.get("MMGL_FFN_PITCH", "1") != "0"      # A/B switch
+
+
+def _ffn_pitch(M, N, K, dtype):
+    """Row pitch (elements) for the [M, N] hidden buffer between the two linears of a frozen FFN.  A power-of-two row size
+    (8192 bf16 = 16 KiB) costs the persistent GEMM ~3 % at that shape (1049 vs 1015 us, tools/probes/gemm_pitch2.py): the buffer
+    and its gradient get 128 extra columns of pitch when all four GEMMs that touch them take strided operands (fast path)."""
+    if dtype != torch.bfloat16 or (N * 2) % 8192 or not _FFN_PITCH:
+        return N
+    P, L = N + 128, lib()
+    if L.mmgl_gemm_nt_fast(M, N, K, K, K, P, _lib.BF16) and L.mmgl_gemm_nt_fast(M, K, N, P, N, K, _lib.BF16):
+        return P
+    return N
+
+
+def _row_strided(t2, cols, n_out):
+    """t2 [M, cols] as a GEMM operand: itself when it is row-major with unit column stride and a row pitch the fast path
+    takes, else a contiguous copy."""
+    if t2.is_contiguous():
+        return t2
+    if (t2.stride(1) == 1 and t2.stride(0) >= cols and t2.stride(0) % 8 == 0 and t2.dtype == torch.bfloat16
+            and lib().mmgl_gemm_nt_fast(t2.shape[0], n_out, cols, t2.stride(0), cols, n_out, _lib.BF16)):
+        return t2
+    return t2.contiguous()
+
+
 class _FrozenLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, mask_dx, premasked, residual=None):
         require_cuda(x, weight)
         K, N = weight.shape[1], weight.shape[0]
-        x2 = x.reshape(-1, K)
-        if not x2.is_contiguous():
-            x2 = x2.contiguous()
+        x2 = _row_strided(x.reshape(-1, K), K, N)
         w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
         b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
         kq = 8 if x.dtype == torch.bfloat16 else 4
         if K % kq == 0 and N % 8 == 0:
             # the output is allocated in its final shape and returned as is (not a view made inside this Function): consumers
             # such as the in-place rotary embedding may then modify it
-            out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
-            r2 = None if residual is None else residual.reshape(-1, N).contiguous()
-            y = gemm_nt(x2, w.contiguous(), b, residual=r2, act=act, out=out.view(-1, N))
+            pitch = _ffn_pitch(x2.shape[0], N, K, x.dtype) if (premasked and residual is None) else N
+            if pitch != N:                   # fc1 of a frozen FFN: the consumer (fc2, mask_dx) reads it with its row stride
+                out = torch.empty(*x.shape[:-1], pitch, dtype=x.dtype, device=x.device)[..., :N]
+                y = gemm_nt(x2, w.contiguous(), b, act=act, out=out.reshape(-1, N))
+            else:
+                out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+                r2 = None if residual is None else residual.reshape(-1, N).contiguous()
+                y = gemm_nt(x2, w.contiguous(), b, residual=r2, act=act, out=out.view(-1, N))
         else:
             out = None
             y = _gemm_nt_padded(x2, w.contiguous(), b, act=act)
@@ -818,8 +853,7 @@ class _FrozenLinear(torch.autograd.Function):
         weight, y, xmask = ctx.saved_tensors
         N, K = weight.shape
         g = dy.reshape(-1, N)
-        if not g.is_contiguous():
-            g = g.contiguous()
+        g = _row_strided(g, N, K) if ctx.act == 0 else g.contiguous()
         if ctx.act == 1:
             gm = torch.empty_like(g)
             _lib.call("mmgl_relu_bwd", dict(bytes=3.0 * g.numel() * g.element_size()), ptr(g), ptr(y), ptr(gm), g.numel(), dtype_code(g), stream_ptr())
@@ -827,7 +861,7 @@ class _FrozenLinear(torch.autograd.Function):
         elif ctx.act:
             raise RuntimeError("frozen_linear: only the ReLU epilogue is differentiable")
         dx = frozen_dgrad(g, weight, zmask=xmask)
-        return dx.view(ctx.xshape), None, None, None, None, None, (dy if ctx.has_resid else None)
+        return dx.reshape(ctx.xshape), None, None, None, None, None, (dy if ctx.has_resid else None)
 
 
 def frozen_linear(x, weight, bias, relu=False, mask_dx=False, bwd_premasked=False, act=None, residual=None):
