@@ -251,8 +251,14 @@ int mmgl_adamw_step(void* param, float* master, const void* grad, float* exp_avg
  * ldx / ldw / ldy: row strides in elements (residual and zmask share ldy); the composed path needs dense operands.
  * mmgl_relu_bwd: out = dy * (y > 0), the backward of a stand-alone ReLU epilogue (in place allowed). */
 int mmgl_gemm_nt_fast(int M, int N, int K, int ldx, int ldw, int ldy, int dtype);
+/* workspace: shapes with fewer 256x256 output tiles than the chip has CUs and a long contraction (the reference's batch of 4:
+ * M = 2560, K >= 3072) are cut into K-split work items whose fp32 partial tiles live in caller memory, like every other
+ * scratch of this library (no allocation inside).  mmgl_gemm_nt_workspace returns the bytes that takes (0 for every other
+ * shape); with workspace == NULL or fewer bytes the same kernel runs unsplit (same result up to fp32 summation order). */
+size_t mmgl_gemm_nt_workspace(int M, int N, int K, int ldx, int ldw, int ldy, int dtype);
 int mmgl_gemm_nt(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, const void* zmask,
-                 void* y, int ldy, int M, int N, int K, int act, float out_scale, int dtype, void* stream);
+                 void* y, int ldy, int M, int N, int K, int act, float out_scale, void* workspace, size_t workspace_bytes,
+                 int dtype, void* stream);
 int mmgl_relu_bwd(const void* dy, const void* y, void* out, size_t n, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -61,7 +61,8 @@ SIGNATURES = {
     "mmgl_add_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, F, U, I, P]),
     "mmgl_activation_fwd": (I, [P, P, Z, I, I, P]),
     "mmgl_gemm_nt_fast": (I, [I, I, I, I, I, I, I]),
-    "mmgl_gemm_nt": (I, [P, I, P, I, P, P, P, P, I, I, I, I, I, F, I, P]),
+    "mmgl_gemm_nt_workspace": (Z, [I, I, I, I, I, I, I]),
+    "mmgl_gemm_nt": (I, [P, I, P, I, P, P, P, P, I, I, I, I, I, F, P, Z, I, P]),
     "mmgl_relu_bwd": (I, [P, P, P, Z, I, P]),
     "mmgl_rope_inplace": (I, [P, P, Z, I, I, I, I, I, I, I, P]),
     "mmgl_swiglu_fwd": (I, [P, P, Z, I, I, P]),

@@ -402,8 +402,7 @@ int launch_gemm(const T* X, const T* W, T* Y, const T* bias, int M, int N, int K
         MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm: K (%d) must be a multiple of %d and N (%d) of 4", K, VN, N);
     if constexpr (sizeof(T) == 2) {
         // persistent ping-pong kernel (gemm8p.hip) whenever the shape gives it enough 256x256 tiles
-        if (!X2 && !accumulate && tune_gemm_8p() && gemm8p_supported(M, N, K, K, K, N) &&
-            (cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles() || gemm8p_use_splits(M, N, K))) {
+        if (!X2 && !accumulate && tune_gemm_8p() && gemm8p_supported(M, N, K, K, K, N) && cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles()) {
             if (zmask_done) *zmask_done = zmask != nullptr;
             return launch_gemm8p((const bf16*)X, K, (const bf16*)W, K, (bf16*)Y, N, (const bf16*)bias, nullptr, (const bf16*)zmask, M, N, K, act, scale, st);
         }
@@ -796,7 +795,14 @@ inline int tt256_splits(int RA, int RB, int K) {
         if (tiles * s >= 192 && K % (64 * s) == 0 && K / s >= 1024) return s;
     return 0;
 }
+inline size_t tt256_partial_bytes_wgrad(int RA, int RB, int K);
+// the split-partial region of a linear's backward workspace: the weight gradient's K-split tiles (RA = in, RB = out features,
+// contraction over the M rows) or, before them on the same stream, the dgrad's ([M, in] outputs, contraction over out features)
 inline size_t tt256_partial_bytes(int RA, int RB, int K) {
+    const size_t a = tt256_partial_bytes_wgrad(RA, RB, K), b = align_up(gemm8p_split_bytes(K, RA, RB), 256);
+    return a > b ? a : b;
+}
+inline size_t tt256_partial_bytes_wgrad(int RA, int RB, int K) {
     int s = tt256_splits(RA, RB, K);
     const int s8 = gemm8p_tt_splits(RA, RB, K);
     if (s8 > s) s = s8;
@@ -1140,8 +1146,16 @@ int linear_bwd(const T* dy, const T* y, const T* x, const T* W, T* dx, T* dW, T*
                 T* Wt = (T*)(ws + bf16_wt_offset(M, N, act));
                 rc = launch_transpose<T>(W, nullptr, Wt, nullptr, N, K, 1.f, 0, st);
                 bool masked = false;
-                if (!rc) rc = launch_gemm<T>((const T*)a, Wt, dx, nullptr, M, K, N, MMGL_ACT_NONE, sc, 0, nullptr, nullptr, 0, st,
-                                             mask_dx ? x : nullptr, &masked);
+                if (!rc && tune_gemm_8p() && gemm8p_supported(M, K, N, N, N, K) && cdiv(M, 256) * cdiv(K, 256) < tune_gemm_8p_min_tiles() &&
+                    gemm8p_use_splits(M, K, N)) {
+                    // few tiles (the reference's batch): K-split work items, partial tiles in the region the weight gradient's
+                    // split partials use afterwards (same stream: the dgrad has consumed them by then)
+                    rc = launch_gemm8p((const bf16*)a, N, (const bf16*)Wt, N, (bf16*)dx, K, nullptr, nullptr, mask_dx ? (const bf16*)x : nullptr,
+                                       M, K, N, MMGL_ACT_NONE, sc, st, (float*)(ws + bf16_part_offset(M, N, K, act)), gemm8p_split_bytes(M, K, N));
+                    masked = mask_dx;
+                } else if (!rc)
+                    rc = launch_gemm<T>((const T*)a, Wt, dx, nullptr, M, K, N, MMGL_ACT_NONE, sc, 0, nullptr, nullptr, 0, st,
+                                        mask_dx ? x : nullptr, &masked);
                 if (!rc && mask_dx && !masked) rc = launch_relu_mask<T>(dx, x, dx, (size_t)M * K, 1.f, st);
             } else {
                 rc = launch_gemm_tx(false, (const bf16*)W, K, a, N, nullptr, (bf16*)dx, K, M, N, sc, 0, st);
@@ -1227,17 +1241,25 @@ extern "C" int mmgl_gemm_nt_fast(int M, int N, int K, int ldx, int ldw, int ldy,
            (cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles() || gemm8p_use_splits(M, N, K));
 }
 
+extern "C" size_t mmgl_gemm_nt_workspace(int M, int N, int K, int ldx, int ldw, int ldy, int dtype) {
+    if (dtype != MMGL_BF16 || !tune_gemm_8p() || !gemm8p_supported(M, N, K, ldx, ldw, ldy)) return 0;
+    if (cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles() || !gemm8p_use_splits(M, N, K)) return 0;
+    return align_up(gemm8p_split_bytes(M, N, K), 256);
+}
+
 extern "C" int mmgl_gemm_nt(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, const void* zmask,
-                            void* y, int ldy, int M, int N, int K, int act, float out_scale, int dtype, void* stream) {
+                            void* y, int ldy, int M, int N, int K, int act, float out_scale, void* workspace, size_t workspace_bytes,
+                            int dtype, void* stream) {
     MMGL_CHECK_ARG(x && W && y, "mmgl_gemm_nt: null pointer");
     MMGL_CHECK_ARG(act >= 0 && act <= 4, "mmgl_gemm_nt: unknown activation %d", act);
     // K may exceed x's row length by less than one 128-wide K step when the matching columns of W are zero padding (the
     // contraction over a vocabulary that is no multiple of 128): the tail of a row then reads the head of the next one
     MMGL_CHECK_ARG(ldx + 127 >= K && ldw >= K && ldy >= N, "mmgl_gemm_nt: leading dimensions (%d, %d, %d) smaller than the rows (K=%d, N=%d)", ldx, ldw, ldy, K, N);
     hipStream_t st = (hipStream_t)stream;
+    // few-tile shapes run as K-split work items when the caller brought mmgl_gemm_nt_workspace() bytes, unsplit otherwise
     if (mmgl_gemm_nt_fast(M, N, K, ldx, ldw, ldy, dtype))
         return launch_gemm8p((const bf16*)x, ldx, (const bf16*)W, ldw, (bf16*)y, ldy, (const bf16*)bias, (const bf16*)residual,
-                             (const bf16*)zmask, M, N, K, act, out_scale, st);
+                             (const bf16*)zmask, M, N, K, act, out_scale, st, (float*)workspace, workspace_bytes);
     if (ldx != K || ldw != K || ldy != N)
         MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "mmgl_gemm_nt: strided operands (ld %d %d %d) need the bf16 fast path (K %% 128 == 0, N %% 16 == 0, "
                   ">= %d tiles of 256x256); got M=%d N=%d K=%d dtype=%d", ldx, ldw, ldy, tune_gemm_8p_min_tiles(), M, N, K, dtype);

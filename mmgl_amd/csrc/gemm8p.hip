@@ -615,8 +615,10 @@ bool gemm8p_supported(int M, int N, int K, int ldx, int ldw, int ldy) {
            (long long)M * ldx * 2 < 0xffffffffLL && (long long)N * ldw * 2 < 0xffffffffLL;
 }
 
+size_t gemm8p_split_bytes(int M, int N, int K) { return (size_t)gemm8p_splits(M, N, K) * M * N * sizeof(float); }
+
 int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, const bf16* resid,
-                  const bf16* zmask, int M, int N, int K, int act, float scale, hipStream_t st) {
+                  const bf16* zmask, int M, int N, int K, int act, float scale, hipStream_t st, float* part, size_t part_bytes) {
     if (!gemm8p_supported(M, N, K, ldx, ldw, ldy))
         MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm8p: shape M=%d N=%d K=%d (ld %d %d %d) not supported", M, N, K, ldx, ldw, ldy);
     P8Args a;
@@ -640,21 +642,10 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
             if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
     }
-    // few-tile outputs (the reference's batch of 4: M = 2560): K-split work items with fp32 partial tiles, folded (with the whole
-    // epilogue) by p8_splitk_finish_kernel.  The partial buffer is a process-wide scratch area: launches are ordered by `st`
-    // (one stream, like every caller of this library); it only grows.
-    const int nsplit = gemm8p_splits(M, N, K);
+    // few-tile outputs (the reference's batch of 4: M = 2560): K-split work items with fp32 partial tiles in the CALLER's scratch
+    // (gemm8p_split_bytes), folded -- with the whole epilogue -- by p8_splitk_finish_kernel.  Without scratch the tile is not split.
+    const int nsplit = (part && part_bytes >= gemm8p_split_bytes(M, N, K)) ? gemm8p_splits(M, N, K) : 0;
     if (nsplit) {
-        static float* part = nullptr;
-        static size_t part_bytes = 0;
-        const size_t need = (size_t)nsplit * M * N * sizeof(float);
-        if (need > part_bytes) {
-            if (part && hipStreamSynchronize(st) == hipSuccess) (void)hipFree(part);
-            part = nullptr;
-            part_bytes = 0;
-            if (hipMalloc((void**)&part, need) != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "gemm8p: cannot allocate %zu B of split-K scratch", need);
-            part_bytes = need;
-        }
         a.nsplit = nsplit;
         a.part = part;
         const int items = a.total * nsplit, g = items < n_cu ? items : n_cu;

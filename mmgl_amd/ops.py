@@ -742,11 +742,13 @@ def gemm_nt(x2, w, bias=None, residual=None, zmask=None, act=0, out_scale=1.0, K
     for name, t in (("zmask", zmask), ("residual", residual)):
         if t is not None and (t.stride(1) != 1 or t.stride(0) != y.stride(0)):
             raise ValueError(f"gemm_nt: {name} must share the output's row stride ({t.stride(0)} vs {y.stride(0)})")
+    nws = lib().mmgl_gemm_nt_workspace(M, N, K, x2.stride(0), w.stride(0), y.stride(0), dtype_code(x2))
+    ws = torch.empty(nws, dtype=torch.uint8, device=x2.device) if nws else None       # K-split partial tiles (few-tile shapes)
     _lib.call("mmgl_gemm_nt", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x2.element_size(),
                                    tag=f"{M}x{N}x{K}" + ("+b" if bias is not None else "") + ("+z" if zmask is not None else "")
                                        + ("+r" if residual is not None else "") + (f"+a{act}" if act else "")),
               ptr(x2), x2.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(residual), ptr(zmask), ptr(y), y.stride(0), M, N, K, act,
-              float(out_scale), dtype_code(x2), stream_ptr())
+              float(out_scale), ptr(ws), nws, dtype_code(x2), stream_ptr())
     return y
 
 
