@@ -54,7 +54,8 @@ struct P8Args {
     int tiles_m, tiles_n, total;
     int nsplit;            // K splits per output tile (1 = none): work item = (tile, split), fp32 partial tiles into `part`
     float* part;           // [nsplit][M][N] fp32 (ACT = 5 kernels)
-    int stagger;           // start delay per CU group in units of 4096 clocks (0 = none)
+    int stagger;           // start delay per CU group in units of 256 clocks (0 = none)
+    int stag_mask;         // CU groups - 1 (power of two; group = CU index within its XCD & mask)
     long long* trace;      // timing experiments only (P8_TRACE builds): [8 waves][64] clock stamps of workgroup trace_wg
     int trace_wg;
 };
@@ -378,8 +379,8 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     // the others compute, each burst drains at the full bandwidth, and the offsets persist because every tile takes the same
     // time.  Costs 3/4 of one tile time once per launch: only worth it over several rounds of tiles.
     if (a.stagger) {
-        const int grp = (blockIdx.x >> 3) & 3;
-        for (int i = 0; i < grp * a.stagger; ++i) __builtin_amdgcn_s_sleep(64);          // 64 x 64 clocks each
+        const int grp = (blockIdx.x >> 3) & a.stag_mask;
+        for (int i = 0; i < grp * a.stagger; ++i) __builtin_amdgcn_s_sleep(4);           // 4 x 64 clocks each
     }
 
     // ---- prologue: units -1 .. 5 of the stream  (Wa(0) | Xa(0) Wb(0) Xb(0) Wa(1) | Xa(1) Wb(1))
@@ -650,6 +651,7 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
         a.part = part;
         const int items = a.total * nsplit, g = items < n_cu ? items : n_cu;
         a.stagger = 0;
+        a.stag_mask = 0;
         a.trace = nullptr;
         hipLaunchKernelGGL((gemm8p_kernel<5, false>), dim3(g), dim3(512), P8_LDS_TOTAL, st, a);
         MMGL_CHECK_LAUNCH("gemm8p (K split)");
@@ -661,9 +663,13 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
         return MMGL_OK;
     }
     const int grid = a.total < n_cu ? a.total : n_cu;
-    static const int stag_on = [] { const char* e = getenv("MMGL_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
-    // a quarter of a tile time, ~11 clocks per unit of K (256 x 256 x K MACs at the sustained rate), when there are >= 3 rounds
-    a.stagger = (stag_on && a.total >= 3 * grid) ? (K * 11 * stag_on + 2048) / 4096 : 0;
+    // MMGL_GEMM_STAGGER = start offset between CU groups in clocks, MMGL_GEMM_STAGGER_GROUPS = 2 / 4 / 8 / 16 / 32 groups
+    static const int stag_clk = [] { const char* e = getenv("MMGL_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+    static const int stag_grp = [] { const char* e = getenv("MMGL_GEMM_STAGGER_GROUPS"); const int g = e ? atoi(e) : 4;
+                                     return (g >= 2 && g <= 32 && !(g & (g - 1))) ? g : 4; }();
+    static const int stag_rounds = [] { const char* e = getenv("MMGL_GEMM_STAGGER_ROUNDS"); return e ? atoi(e) : 2; }();
+    a.stagger = (stag_clk > 0 && a.total >= stag_rounds * grid) ? (stag_clk + 128) / 256 : 0;
+    a.stag_mask = stag_grp - 1;
     a.trace = nullptr;
     a.trace_wg = 0;
 #if P8_TRACE
