@@ -51,14 +51,14 @@ def _reference_run(data, accum, steps, lr):
     return torch.cat([p.detach().reshape(-1) for p in m.parameters() if p.requires_grad])
 
 
-def _worker(rank, world, port, data, accum, steps, lr, bucket_mb, out):
+def _worker(rank, world, port, data, accum, steps, lr, bucket_mb, out, tail_mb=32):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mmgl_amd.distributed import DataParallelEngine
     torch.manual_seed(0 if rank == 0 else 123)         # rank 1 starts from different weights: the constructor must broadcast
     m = Toy()
-    eng = DataParallelEngine(m, lr=lr, betas=(0.9, 0.95), weight_decay=0.01, bucket_mb=bucket_mb, fused=False)
+    eng = DataParallelEngine(m, lr=lr, betas=(0.9, 0.95), weight_decay=0.01, bucket_mb=bucket_mb, tail_mb=tail_mb, fused=False)
     assert eng.names[0].startswith("neighbor_layers.2") and eng.names[-1].startswith("text_embeddings")
     it = 0
     for s in range(steps):
@@ -92,6 +92,35 @@ def test_two_rank_engine_matches_single_process(tmp_path, accum, bucket_mb):
     assert res["exchange_bytes"] == steps * res["numel"] * 4
     if bucket_mb == 0:
         assert res["nbuckets"] > 1
+
+
+def test_two_rank_engine_with_a_tail_bucket(tmp_path):
+    """One big bucket whose last-ready part is cut off as a small tail bucket (the exposed exchange): same result."""
+    steps, lr, accum = 3, 1e-2, 2
+    g = torch.Generator().manual_seed(6)
+    data = [[torch.randn(4, 6, generator=g) for _ in range(steps * accum)] for _ in range(2)]
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, nprocs=2, args=(2, _free_port(), data, accum, steps, lr, 256, out, 1e-4), join=True)
+    res = torch.load(out)
+    ref = _reference_run(data, accum, steps, lr)
+    assert res["nbuckets"] == 2
+    assert torch.equal(res["params"], res["other"]), "ranks diverged"
+    assert torch.allclose(res["params"], ref, rtol=1e-5, atol=1e-6), (res["params"] - ref).abs().max()
+    assert res["exchange_bytes"] == steps * res["numel"] * 4
+
+
+def test_tail_bucket_layout():
+    """Buckets tile the flat gradient without gaps, in order; the last one holds at most tail_mb (or one parameter)."""
+    from mmgl_amd.distributed import DataParallelEngine
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(*[torch.nn.Linear(64, 64) for _ in range(12)])
+    eng = DataParallelEngine(m, fused=False, bucket_mb=0.05, tail_mb=0.02)       # 16.6 KB per layer
+    bs = eng.buckets
+    assert bs[0]["start"] == 0 and bs[-1]["end"] == eng.numel and all(a["end"] == b["start"] for a, b in zip(bs, bs[1:]))
+    assert [i for b in bs for i in b["members"]] == list(range(len(eng.params)))
+    assert len(bs) >= 2 and (bs[-1]["end"] - bs[-1]["start"]) * 4 <= 0.02 * (1 << 20)
+    for b in bs:
+        assert b["start"] == eng.offsets[b["members"][0]]
 
 
 def test_engine_single_process_state_dict_roundtrip():
