@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""How much does a co-resident kernel (a collective's 16-64 workgroups on a side stream) cost the persistent GEMM, whose grid is one
+workgroup per CU with the whole LDS / register file of its CU?   python tools/probes/gemm_coresident.py"""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from mmgl_amd import ops  # noqa: E402
+
+occ = ctypes.CDLL(os.path.join(ROOT, "build_probe", "liboccupier.so"))
+occ.occupier_spin.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
+
+
+def main():
+    M, N, K = 40960, 2048, 2048
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    for _ in range(5):
+        ops.gemm_nt(x, w, out=y)
+    torch.cuda.synchronize()
+    for wgs in (0, 8, 16, 32, 64):
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            if wgs:
+                occ.occupier_spin(wgs, 100 * 1000 * 6, side.cuda_stream)      # 6 ms of the 100 MHz wall clock: covers the loop below
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                ops.gemm_nt(x, w, out=y)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 8 * 1e3)
+        print(f"occupier workgroups {wgs:3d}: {M}x{N}x{K} {best:7.1f} us per GEMM", flush=True)
+
+
+if __name__ == "__main__":
+    main()
