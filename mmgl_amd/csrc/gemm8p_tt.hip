@@ -21,6 +21,9 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
+#ifndef T8_ABLATE
+#define T8_ABLATE 0        // timing experiments only (1: every LDS-DMA reads K tile 0, 2: fragments read once, 3: no LDS-DMA, 4: no wait for the LDS-DMA, 5: ds_read_b128 in place of the two transpose reads); never set in a shipped build
+#endif
 constexpr int T8_UNIT = 16384;
 constexpr int T8_LDS = 8 * T8_UNIT;
 
@@ -51,6 +54,9 @@ __device__ __forceinline__ bf16x8 t8_frag(const char* unit, int blk, int ks, int
     const int i = lane & 15, g = lane >> 4;
     const int row = ks * 32 + 4 * g + (i >> 2);             // row + 16 has the same (row & 7)
     const char* p = unit + row * 256 + ((blk ^ (row & 7)) << 5) + (i & 3) * 8;
+#if T8_ABLATE == 5
+    return *(const bf16x8*)(unit + row * 256 + ((blk ^ (row & 7)) << 5) + (i & 1) * 16);      // one plain 16-byte read per fragment (wrong data, same bytes)
+#endif
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * 256));
     bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -188,15 +194,15 @@ __global__ __launch_bounds__(512) void gemm8p_tt_kernel(T8Args a) {
 
 #define T8_PHASE(READ, TY, SLOT, DK, FB, FA, J0, T0)                                             \
     do {                                                                                         \
-        READ;                                                                                    \
-        {                                                                                        \
+        if (T8_ABLATE != 2 || kt == 0) { READ; }                                                 \
+        if (T8_ABLATE != 3) {                                                                    \
             const int kk_ = kt + (DK);                                                           \
             const bool nx_ = kk_ >= nk;                                                          \
-            const int ki_ = nx_ ? kk_ - nk : kk_;                                                \
+            const int ki_ = T8_ABLATE == 1 ? 0 : (nx_ ? kk_ - nk : kk_);                         \
             if ((TY) & 1) stage((TY), (SLOT), nx_ ? dAn : dAc, ki_ * stepA);                     \
             else stage((TY), (SLOT), nx_ ? dBn : dBc, ki_ * stepB);                              \
         }                                                                                        \
-        T8_VMCNT(10);                                                                            \
+        if (T8_ABLATE != 4) T8_VMCNT(10);                                                        \
         T8_BARRIER();                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         __builtin_amdgcn_s_setprio(1);                                                           \

@@ -5,7 +5,8 @@
 filt=$1; out=$2; shift 3
 export TMPDIR=/tmp
 rm -rf /tmp/pmc_sq
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS \
+ctrs=${PMC_SQ_COUNTERS:-SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS}
+rocprofv3 --kernel-trace --pmc $ctrs \
   --output-format csv -d /tmp/pmc_sq -o p -- "$@" > /tmp/pmc_sq.log 2>&1
 python - "$filt" > "$out" <<'PY'
 import csv, glob, sys, collections, re

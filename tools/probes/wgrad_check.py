@@ -43,5 +43,9 @@ def run(M, N, K, check=True):
         print(f"M={M} N={N} K={K} {name}: {t*1e6:.1f} us {fl/t/1e12:.1f} TF", flush=True)
 
 
+if len(sys.argv) > 1:        # python tools/probes/wgrad_check.py M,N,K [M,N,K ...]
+    for arg in sys.argv[1:]:
+        run(*(int(v) for v in arg.split(",")), check=False)
+    sys.exit(0)
 for shape in [(40960, 2048, 2048), (40960, 8192, 2048), (40960, 2048, 8192), (4096, 2048, 2048), (17408, 4096, 4096), (17408, 11008, 4096)]:
     run(*shape)
