@@ -24,6 +24,9 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 #ifndef T8_ABLATE
 #define T8_ABLATE 0        // timing experiments only (1: every LDS-DMA reads K tile 0, 2: fragments read once, 3: no LDS-DMA, 4: no wait for the LDS-DMA, 5: ds_read_b128 in place of the two transpose reads); never set in a shipped build
 #endif
+#ifndef T8_ROLL
+#define T8_ROLL 1          // 1: fragments of the next phase are read inside the MFMA cluster (rolling reloads); 0: a read block ahead of every phase
+#endif
 constexpr int T8_UNIT = 16384;
 constexpr int T8_LDS = 8 * T8_UNIT;
 
@@ -64,7 +67,7 @@ __device__ __forceinline__ bf16x8 t8_frag(const char* unit, int blk, int ks, int
 }
 
 __global__ __launch_bounds__(512) void gemm8p_tt_kernel(T8Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -93,26 +96,60 @@ __global__ __launch_bounds__(512) void gemm8p_tt_kernel(T8Args a) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (valid ? off : 0)), 0, (int)(unsigned)rem, 0x00020000);
     };
 
-    // ---- staging offsets: unit type 0 Ba, 1 Ab, 2 Bb, 3 Aa; a wave moves pieces `wave` and `wave + 8` (4 m-rows of 256 B each)
-    int voff[4][2];
-#pragma unroll
-    for (int ty = 0; ty < 4; ++ty)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (wave + 8 * i) * 4 + (lane >> 4);
-            const int s16 = lane & 15;
-            const int c16 = ((((s16 >> 1) ^ (row & 7)) << 1) | (s16 & 1));      // source 16-byte chunk of this LDS position
-            const int cl = c16 * 8;                                               // first of its 8 unit columns
-            int col, ld;
-            if (!(ty & 1)) { col = (cl >> 6) * 128 + (ty == 2 ? 64 : 0) + (cl & 63); ld = a.ldb; }
-            else { col = (cl >> 5) * 64 + (ty == 1 ? 32 : 0) + (cl & 31); ld = a.lda; }
-            voff[ty][i] = (row * ld + col) * 2;
-        }
+    // ---- staging offsets: unit type 0 Ba, 1 Ab, 2 Bb, 3 Aa; a wave moves pieces `wave` and `wave + 8` (4 m-rows of 256 B each).
+    // One lane offset per operand: the b half of a unit type is 128 / 64 bytes further, piece wave + 8 is 32 rows further (both
+    // added to the scalar offset) and has the same row & 7, hence the same source chunk.
+    int voffB, voffA;
+    {
+        const int row = wave * 4 + (lane >> 4);
+        const int s16 = lane & 15;
+        const int c16 = ((((s16 >> 1) ^ (row & 7)) << 1) | (s16 & 1));      // source 16-byte chunk of this LDS position
+        const int cl = c16 * 8;                                               // first of its 8 unit columns
+        voffB = (row * a.ldb + (cl >> 6) * 128 + (cl & 63)) * 2;
+        voffA = (row * a.lda + (cl >> 5) * 64 + (cl & 31)) * 2;
+    }
+    const int rows32B = 32 * a.ldb * 2, rows32A = 32 * a.lda * 2;
     auto stage = [&](int ty, int slot, __amdgpu_buffer_rsrc_t rs, int soff) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + slot * T8_UNIT + (wave + 8 * i) * 1024), 16, voff[ty][i], soff, 0, 0);
+        lds_void* d0 = (lds_void*)(smem + slot * T8_UNIT + wave * 1024);
+        lds_void* d1 = (lds_void*)(smem + slot * T8_UNIT + (wave + 8) * 1024);
+        // (the instruction's immediate offset would move the LDS address too: the b halves go through the scalar offset)
+        const int vo = (ty & 1) ? voffA : voffB;
+        const int so = soff + (ty == 2 ? 128 : ty == 1 ? 64 : 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, d0, 16, vo, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, d1, 16, vo, so + ((ty & 1) ? rows32A : rows32B), 0, 0);
     };
+    // ---- fragment addresses.  Byte offset of lane (i, g)'s first transpose read of fragment (slot, blk, ks):
+    //   slot * 16384 + ks * 8192 + row * 256 + ((blk ^ (row & 7)) << 5) + (i & 3) * 8,   row = 4 g + (i >> 2)
+    // The lane part L = row * 256 + (i & 3) * 8 has no bits 5-7, so L + ((blk ^ r7) << 5) = (L | r7 << 5) ^ (blk << 5): ONE lane
+    // constant per operand side (with the wave's part of blk folded in: wr << 7 / wc << 6), the fragment index as an XOR with
+    // an inline constant at the point of use (v_xor in volatile asm: not hoisted, so not 30 loop-invariant address registers),
+    // slot and ks in the instruction's offset field (slots 4-7 through a second base, 64 KiB up).
+    int fbase_b, fbase_a;
+    {
+        const int i = lane & 15, g = lane >> 4;
+        const int row = 4 * g + (i >> 2);
+        const int L = (row * 256 + (i & 3) * 8) | ((row & 7) << 5);
+        const int lds0 = (int)(unsigned)(size_t)(lds_void*)smem;       // 0 (no static LDS in this kernel); a multiple of 1024 by declaration
+        fbase_b = (L ^ (wr << 7)) + lds0;
+        fbase_a = (L ^ (wc << 6)) + lds0;
+    }
+    const int fbase_b_hi = fbase_b + 65536, fbase_a_hi = fbase_a + 65536;
+    // dst = fragment (SLOT, SUB, KS) of the side whose lane bases are BLO / BHI (SUB: j for B, t for A; all literals).
+    // The two transpose reads are INLINE ASM on purpose: behind the builtin, hipcc's waitcnt pass cannot tell the read from the
+    // LDS-DMA writes in flight and puts `s_waitcnt vmcnt(0)` in front of every one of them -- the whole 6-unit prefetch drained in
+    // every phase (that, not the instruction count, held this kernel at 1.13 PF; the NT kernel's plain 16-byte reads are not
+    // affected).  The price: the compiler no longer counts lgkmcnt for these registers, so every phase waits for lgkmcnt(0)
+    // right after its barrier, before its first MFMA (the reads were issued a partner-cluster earlier).
+#define T8_FRAG(dst, BLO, BHI, SLOT, SUB, KS)                                                                        \
+    do {                                                                                                             \
+        int ad_;                                                                                                     \
+        if ((SUB) == 0) ad_ = ((SLOT) >= 4 ? BHI : BLO);                                                              \
+        else asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ad_) : "i"(((SUB) & 3) << 5), "v"((SLOT) >= 4 ? BHI : BLO));   \
+        bf16x4 lo_, hi_;                                                                                             \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo_) : "v"(ad_), "i"(((SLOT) & 3) * T8_UNIT + (KS) * 8192)); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi_) : "v"(ad_), "i"(((SLOT) & 3) * T8_UNIT + (KS) * 8192 + 4096)); \
+        dst = bf16x8{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                                 \
+    } while (0)
     // fragments: B side (8 x 16 rb columns per wave, 4 per unit), A side (4 x 16 ra columns per wave, 2 per unit)
     auto rdB = [&](bf16x8 (&f)[2][4], int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -189,9 +226,20 @@ __global__ __launch_bounds__(512) void gemm8p_tt_kernel(T8Args a) {
     T8_VMCNT(10);
     T8_BARRIER();
     rdA(faA, 7);
+#if T8_ROLL
+    rdB(fb, 0);
+#endif
     T8_LGKM0();
     if (wr) T8_BARRIER();
 
+#if !T8_ROLL
+    // the read-block form (a block of transpose reads ahead of every phase's barrier), kept for comparison: same inline-asm reads
+#define T8_RDB(S) do { T8_FRAG(fb[0][0], fbase_b, fbase_b_hi, S, 0, 0); T8_FRAG(fb[0][1], fbase_b, fbase_b_hi, S, 1, 0); \
+                       T8_FRAG(fb[0][2], fbase_b, fbase_b_hi, S, 2, 0); T8_FRAG(fb[0][3], fbase_b, fbase_b_hi, S, 3, 0); \
+                       T8_FRAG(fb[1][0], fbase_b, fbase_b_hi, S, 0, 1); T8_FRAG(fb[1][1], fbase_b, fbase_b_hi, S, 1, 1); \
+                       T8_FRAG(fb[1][2], fbase_b, fbase_b_hi, S, 2, 1); T8_FRAG(fb[1][3], fbase_b, fbase_b_hi, S, 3, 1); } while (0)
+#define T8_RDA(F, S) do { T8_FRAG(F[0][0], fbase_a, fbase_a_hi, S, 0, 0); T8_FRAG(F[0][1], fbase_a, fbase_a_hi, S, 1, 0); \
+                          T8_FRAG(F[1][0], fbase_a, fbase_a_hi, S, 0, 1); T8_FRAG(F[1][1], fbase_a, fbase_a_hi, S, 1, 1); } while (0)
 #define T8_PHASE(READ, TY, SLOT, DK, FB, FA, J0, T0)                                             \
     do {                                                                                         \
         if (T8_ABLATE != 2 || kt == 0) { READ; }                                                 \
@@ -204,6 +252,7 @@ __global__ __launch_bounds__(512) void gemm8p_tt_kernel(T8Args a) {
         }                                                                                        \
         if (T8_ABLATE != 4) T8_VMCNT(10);                                                        \
         T8_BARRIER();                                                                            \
+        T8_LGKM0();                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         __builtin_amdgcn_s_setprio(1);                                                           \
         T8_MM(FB, FA, J0, T0, 0, 15);                                                            \
@@ -217,15 +266,79 @@ __global__ __launch_bounds__(512) void gemm8p_tt_kernel(T8Args a) {
 
     for (;;) {
         for (int kt = 0; kt < nk; kt += 2) {
-            T8_PHASE(rdB(fb, 0), 2, 6, 1, fb, faA, 0, 0);
-            T8_PHASE(rdA(faB, 1), 3, 7, 2, fb, faB, 0, 2);
-            T8_PHASE(rdB(fb, 2), 0, 0, 2, fb, faB, 4, 2);
-            T8_PHASE(rdA(faB, 3), 1, 1, 2, fb, faA, 4, 0);
-            T8_PHASE(rdB(fb, 4), 2, 2, 2, fb, faB, 0, 0);
-            T8_PHASE(rdA(faA, 5), 3, 3, 3, fb, faA, 0, 2);
-            T8_PHASE(rdB(fb, 6), 0, 4, 3, fb, faA, 4, 2);
-            T8_PHASE(rdA(faA, 7), 1, 5, 3, fb, faB, 4, 0);
+            T8_PHASE(T8_RDB(0), 2, 6, 1, fb, faA, 0, 0);
+            T8_PHASE(T8_RDA(faB, 1), 3, 7, 2, fb, faB, 0, 2);
+            T8_PHASE(T8_RDB(2), 0, 0, 2, fb, faB, 4, 2);
+            T8_PHASE(T8_RDA(faB, 3), 1, 1, 2, fb, faA, 4, 0);
+            T8_PHASE(T8_RDB(4), 2, 2, 2, fb, faB, 0, 0);
+            T8_PHASE(T8_RDA(faA, 5), 3, 3, 3, fb, faA, 0, 2);
+            T8_PHASE(T8_RDB(6), 0, 4, 3, fb, faA, 4, 2);
+            T8_PHASE(T8_RDA(faA, 7), 1, 5, 3, fb, faB, 4, 0);
         }
+#else
+    // Rolling fragment reloads.  A fragment costs TWO transpose reads, a phase that refills the eight B fragments issues 16 of them,
+    // and as a block in front of the MFMAs that does not fit beside the partner wave's 272 MFMA clocks (the NT kernel
+    // with half the LDS instructions runs 40 % faster on the same flops).  So no phase reads ahead of its barrier any more: the
+    // fragments of phase p+1 are read INSIDE the MFMA cluster of phase p, each into its register right after the last MFMA that
+    // uses the old contents (B fragments, and an A buffer that is in use) or spread over the cluster (an A buffer that is free).
+    // Unit p+1 has landed by then (the vmcnt + barrier of phase p already guaranteed it), its slot is re-staged three phases later.
+#define T8_M1(FB, FA, J0, T0, i) mma16(acc[(T0) + ((i) & 1)][(J0) + (((i) >> 1) & 3)], FA[(i) >> 3][(i) & 1], FB[(i) >> 3][((i) >> 1) & 3])
+#define T8_FRB(S, q) T8_FRAG(fb[(q) >> 2][(q) & 3], fbase_b, fbase_b_hi, S, (q) & 3, (q) >> 2)
+#define T8_FRA(F, S, ks, t) T8_FRAG(F[ks][t], fbase_a, fbase_a_hi, S, t, ks)
+    // hooks: what is read after MFMA pair q (q = 0..7; pair 7's second MFMA runs after the hand-over barrier)
+#define T8_HK_B(S, q) T8_FRB(S, q)                                                      /* refill fb, pair by pair */
+#define T8_HK_AFREE(F, S, q) do { if (!((q) & 1)) T8_FRA(F, S, (q) >> 2, ((q) >> 1) & 1); } while (0)   /* a free A buffer: after pairs 0, 2, 4, 6 */
+#define T8_HK_AUSED(F, S, q) do { if ((q) == 3) { T8_FRA(F, S, 0, 0); T8_FRA(F, S, 0, 1); } if ((q) == 7) { T8_FRA(F, S, 1, 0); T8_FRA(F, S, 1, 1); } } while (0)
+#define T8_PHASE2(TY, SLOT, DK, FB, FA, J0, T0, HOOK)                                            \
+    do {                                                                                         \
+        {                                                                                        \
+            const int kk_ = kt + (DK);                                                           \
+            const bool nx_ = kk_ >= nk;                                                          \
+            const int ki_ = nx_ ? kk_ - nk : kk_;                                                \
+            if ((TY) & 1) stage((TY), (SLOT), nx_ ? dAn : dAc, ki_ * stepA);                     \
+            else stage((TY), (SLOT), nx_ ? dBn : dBc, ki_ * stepB);                              \
+        }                                                                                        \
+        T8_VMCNT(10);                                                                            \
+        T8_BARRIER();                                                                            \
+        T8_LGKM0();                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                           \
+        T8_M1(FB, FA, J0, T0, 0); T8_M1(FB, FA, J0, T0, 1); HOOK(0); __builtin_amdgcn_sched_barrier(0);     \
+        T8_M1(FB, FA, J0, T0, 2); T8_M1(FB, FA, J0, T0, 3); HOOK(1); __builtin_amdgcn_sched_barrier(0);     \
+        T8_M1(FB, FA, J0, T0, 4); T8_M1(FB, FA, J0, T0, 5); HOOK(2); __builtin_amdgcn_sched_barrier(0);     \
+        T8_M1(FB, FA, J0, T0, 6); T8_M1(FB, FA, J0, T0, 7); HOOK(3); __builtin_amdgcn_sched_barrier(0);     \
+        T8_M1(FB, FA, J0, T0, 8); T8_M1(FB, FA, J0, T0, 9); HOOK(4); __builtin_amdgcn_sched_barrier(0);     \
+        T8_M1(FB, FA, J0, T0, 10); T8_M1(FB, FA, J0, T0, 11); HOOK(5); __builtin_amdgcn_sched_barrier(0);   \
+        T8_M1(FB, FA, J0, T0, 12); T8_M1(FB, FA, J0, T0, 13); HOOK(6); __builtin_amdgcn_sched_barrier(0);   \
+        T8_M1(FB, FA, J0, T0, 14);                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        T8_BARRIER();                                                                            \
+        T8_M1(FB, FA, J0, T0, 15);                                                               \
+        HOOK(7);                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    } while (0)
+#define T8_H1(q) T8_HK_AFREE(faB, 1, q)
+#define T8_H2(q) T8_HK_B(2, q)
+#define T8_H3(q) T8_HK_AUSED(faB, 3, q)
+#define T8_H4(q) T8_HK_B(4, q)
+#define T8_H5(q) T8_HK_AFREE(faA, 5, q)
+#define T8_H6(q) T8_HK_B(6, q)
+#define T8_H7(q) T8_HK_AUSED(faA, 7, q)
+#define T8_H8(q) T8_HK_B(0, q)
+
+    for (;;) {
+        for (int kt = 0; kt < nk; kt += 2) {
+            T8_PHASE2(2, 6, 1, fb, faA, 0, 0, T8_H1);      // Ba x Aa      | reads Ab   -> faB
+            T8_PHASE2(3, 7, 2, fb, faB, 0, 2, T8_H2);      // Ba x Ab      | reads Bb   -> fb
+            T8_PHASE2(0, 0, 2, fb, faB, 4, 2, T8_H3);      // Bb x Ab      | reads Aa'  -> faB
+            T8_PHASE2(1, 1, 2, fb, faA, 4, 0, T8_H4);      // Bb x Aa      | reads Ba'  -> fb
+            T8_PHASE2(2, 2, 2, fb, faB, 0, 0, T8_H5);      // Ba' x Aa'    | reads Ab'  -> faA
+            T8_PHASE2(3, 3, 3, fb, faA, 0, 2, T8_H6);      // Ba' x Ab'    | reads Bb'  -> fb
+            T8_PHASE2(0, 4, 3, fb, faA, 4, 2, T8_H7);      // Bb' x Ab'    | reads Aa'' -> faA
+            T8_PHASE2(1, 5, 3, fb, faB, 4, 0, T8_H8);      // Bb' x Aa'    | reads Ba'' -> fb
+        }
+#endif
         epilogue();
         if (!have_next) break;
         ++it;
