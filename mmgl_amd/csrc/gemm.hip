@@ -492,6 +492,22 @@ __device__ __forceinline__ bf16x8 tfrag_kmajor_swz(const char* tile, int blk, in
     return r;
 }
 
+// The same fragment through INLINE-ASM transpose reads, for tiles filled by LDS-DMA: behind the builtin, hipcc's waitcnt pass
+// cannot tell the read from the global_load_lds writes in flight and puts `s_waitcnt vmcnt(0)` in front of the first transpose
+// read of every K tile -- the next tile's DMA, issued a few instructions earlier, was waited for before the current tile's
+// MFMAs (no overlap at all).  The caller waits for lgkmcnt(0) itself before it uses the registers.
+__device__ __forceinline__ bf16x8 tfrag_kmajor_swz_asm(const char* tile, int blk, int ks, int lane) {
+    typedef __attribute__((address_space(3))) void lds_v;
+    const int i = lane & 15, g = lane >> 4;
+    const int row = ks * 32 + 4 * g + (i >> 2);
+    const unsigned ad = (unsigned)(size_t)(lds_v*)tile + row * 256 + ((blk ^ (row & 7)) << 5) + (i & 3) * 8;
+    bf16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(hi) : "v"(ad));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+
 template <bool TB, bool MASK, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_tx_kernel(const bf16* __restrict__ Aop, int lda, const bf16* __restrict__ Bop,
                                                       int ldb, const bf16* __restrict__ Ymask, bf16* __restrict__ Out,
@@ -606,24 +622,45 @@ __global__ __launch_bounds__(256) void gemm_tx_kernel(const bf16* __restrict__ A
         }
         const char* tA = sA + buf * TX_TILE_BYTES;
         const char* tB = sB + buf * TX_TILE_BYTES;
+        if constexpr (GLDS) {
+            // all 16 fragments of the K tile up front (inline-asm transpose reads: see tfrag_kmajor_swz_asm), one lgkmcnt(0), 32 MFMAs
+            // under which the next tile's LDS-DMA -- issued above -- stays in flight; it is waited for just before the barrier
+            bf16x8 fa[2][4], fb[2][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if constexpr (GLDS) fa[i] = tfrag_kmajor_swz(tA, wa * 4 + i, ks, lane);
-                else fa[i] = tfrag_kmajor(tA, wa * 4 + i, ks, lane);
-                if constexpr (TB) {
-                    if constexpr (GLDS) fb[i] = tfrag_kmajor_swz(tB, wb * 4 + i, ks, lane);
-                    else fb[i] = tfrag_kmajor(tB, wb * 4 + i, ks, lane);
-                } else fb[i] = rfrag_perm(tB, wb * 64 + i * 16 + x, ks, g);
+                for (int i = 0; i < 4; ++i) {
+                    fa[ks][i] = tfrag_kmajor_swz_asm(tA, wa * 4 + i, ks, lane);
+                    if constexpr (TB) fb[ks][i] = tfrag_kmajor_swz_asm(tB, wb * 4 + i, ks, lane);
+                    else fb[ks][i] = rfrag_perm(tB, wb * 64 + i * 16 + x, ks, g);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16(acc[i][j], fa[ks][i], fb[ks][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    fa[i] = tfrag_kmajor(tA, wa * 4 + i, ks, lane);
+                    if constexpr (TB) fb[i] = tfrag_kmajor(tB, wb * 4 + i, ks, lane);
+                    else fb[i] = rfrag_perm(tB, wb * 64 + i * 16 + x, ks, g);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16(acc[i][j], fa[i], fb[j]);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mma16(acc[i][j], fa[i], fb[j]);
+            if (kt + 1 < nk) store_tile(buf ^ 1);
         }
-        if constexpr (!GLDS) { if (kt + 1 < nk) store_tile(buf ^ 1); }
         __syncthreads();
     }
 #pragma unroll
