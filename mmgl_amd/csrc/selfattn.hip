@@ -74,11 +74,17 @@ __device__ __forceinline__ void online_softmax_row(f32x4 (&s)[4], float& m, f32x
 
 // Register-staged K / V tile (T14 split: the next tile's global loads are issued before the current tile's MFMAs and
 // written to LDS after them, so the HBM/L2 latency of a 64-key tile hides under compute).
+// "These registers are complete": an empty asm that reads them, placed ahead of a loop.  A load issued before a loop and first used
+// inside it stays pending in hipcc's waitcnt scoreboard at the loop header, so every iteration waits with a count that means
+// "the prefetch I just issued as well" -- the next tile's loads drained in the middle of the current tile's MFMAs.
+template <typename V> __device__ __forceinline__ void loaded(const V& v) { asm volatile("" ::"v"(v)); }
+
 template <typename T, typename C, bool K_ROWMAJOR, bool V_ROWMAJOR> struct TileStage {
     typedef typename Elem<T>::v8 v8;
     static constexpr int N = C::SPAD * C::CPR / 256;          // chunks per thread per operand (256 threads)
     v8 kr[N], vr[N];
     uint8_t vb;
+    bool vin;
     __device__ __forceinline__ void load(const T* kbase, const T* vbase, const uint8_t* valid_row, size_t row_stride, int s0, int T_) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -87,7 +93,8 @@ template <typename T, typename C, bool K_ROWMAJOR, bool V_ROWMAJOR> struct TileS
             kr[i] = ok ? *(const v8*)(kbase + (size_t)(s0 + s) * row_stride + c * 8) : vzero<v8>();
             vr[i] = ok ? *(const v8*)(vbase + (size_t)(s0 + s) * row_stride + c * 8) : vzero<v8>();
         }
-        vb = (threadIdx.x < KT && s0 + (int)threadIdx.x < T_) ? (valid_row ? valid_row[s0 + threadIdx.x] : (uint8_t)1) : 0;
+        vin = threadIdx.x < KT && s0 + (int)threadIdx.x < T_;
+        vb = (vin && valid_row) ? valid_row[s0 + threadIdx.x] : (uint8_t)1;
     }
     // branch-free form: rows past the end of the sequence / padding channels fall outside the descriptor and read as 0
     __device__ __forceinline__ void loadb(__amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv, uint32_t row_bytes,
@@ -102,9 +109,11 @@ template <typename T, typename C, bool K_ROWMAJOR, bool V_ROWMAJOR> struct TileS
             kr[i] = buf_load8<T>(rk, off);
             vr[i] = buf_load8<T>(rv, off);
         }
+        // the mask byte is only LOADED here: any arithmetic on it (even the in-range select) would make hipcc wait for it -- the
+        // youngest load of the tile, i.e. vmcnt(0) -- right behind the prefetch instead of after this tile's MFMAs
         const int sv = s0 + (int)(threadIdx.x & (KT - 1));
-        const uint8_t vv = valid_row ? valid_row[min(sv, T_ - 1)] : (uint8_t)1;
-        vb = (sv < T_) ? vv : (uint8_t)0;
+        vb = valid_row ? valid_row[min(sv, T_ - 1)] : (uint8_t)1;
+        vin = sv < T_;
     }
     __device__ __forceinline__ void store(T* Kimg, T* Vimg, uint8_t* vld) const {
 #pragma unroll
@@ -115,7 +124,7 @@ template <typename T, typename C, bool K_ROWMAJOR, bool V_ROWMAJOR> struct TileS
             if constexpr (V_ROWMAJOR) *(v8*)(Vimg + s * C::LD + c * 8) = vr[i];
             else *(v8*)(Vimg + rf_idx<C>(s >> 4, c >> 2, (s & 15) + 16 * (c & 3))) = vr[i];
         }
-        if (threadIdx.x < KT) vld[threadIdx.x] = vb ? (uint8_t)1 : (uint8_t)0;
+        if (threadIdx.x < KT) vld[threadIdx.x] = (vin && vb) ? (uint8_t)1 : (uint8_t)0;
     }
 };
 
@@ -302,6 +311,10 @@ __global__ __launch_bounds__(256) void encattn_fwd_kernel(const T* __restrict__ 
     TileStage<T, C, false, C::TIMG> stg;
     stg.loadb(rk, rv, rb_in, nullptr, 0, len);
     stg.store(Kimg(0), Vimg(0), Vld(0));
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt)
+#pragma unroll
+        for (int dc = 0; dc < C::NDC; ++dc) loaded(qf[qt][dc]);
     __syncthreads();
     for (int j = 0; j < nkt; ++j) {                           // double-buffered tiles, one barrier each (see selfattn_fwd_kernel)
         const T* Kf = Kimg(j & 1);
