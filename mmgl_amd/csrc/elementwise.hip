@@ -192,8 +192,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
     const T* x = logits + (size_t)row * V_;
     float m = -INFINITY, s = 0.f;
     const int nvec = (((size_t)V_ * sizeof(T)) % 16 == 0) ? V_ / VN : 0;      // odd vocab sizes: rows are not 16-B aligned -> scalar path
-    for (int i = threadIdx.x; i < nvec; i += 256) {
-        const V v = ((const V*)x)[i];
+    auto fold = [&](const V& v) __attribute__((always_inline)) {
         float lm = (float)v[0];
 #pragma unroll
         for (int j = 1; j < VN; ++j) lm = fmaxf(lm, (float)v[j]);
@@ -203,7 +202,17 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
         for (int j = 0; j < VN; ++j) acc += __expf((float)v[j] - nm);
         s = s * __expf(m - nm) + acc;
         m = nm;
+    };
+    // four independent 16-byte loads in flight per thread (one load, one wait, nine exps per trip ran at 45 % of the HBM rate)
+    int i = threadIdx.x;
+    for (; i + 768 < nvec; i += 1024) {
+        const V v0 = ((const V*)x)[i], v1 = ((const V*)x)[i + 256], v2 = ((const V*)x)[i + 512], v3 = ((const V*)x)[i + 768];
+        fold(v0);
+        fold(v1);
+        fold(v2);
+        fold(v3);
     }
+    for (; i < nvec; i += 256) fold(((const V*)x)[i]);
     for (int i = nvec * VN + threadIdx.x; i < V_; i += 256) {
         const float a = (float)x[i];
         const float nm = fmaxf(m, a);
@@ -249,8 +258,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
     const float scale = ign ? 0.f : (*dloss) / fmaxf(*count, 1.f);
     const float lse = row_lse[row];
     const int nvec = (((size_t)V_ * sizeof(T)) % 16 == 0) ? V_ / VN : 0;
-    for (int i = threadIdx.x; i < nvec; i += 256) {
-        const V v = ((const V*)x)[i];
+    auto grad = [&](int i, const V& v) __attribute__((always_inline)) {
         V o;
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
@@ -259,7 +267,16 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
             o[j] = (T)(g * scale);
         }
         ((V*)dx)[i] = o;
+    };
+    int i = threadIdx.x;
+    for (; i + 768 < nvec; i += 1024) {                      // four independent loads in flight per thread
+        const V v0 = ((const V*)x)[i], v1 = ((const V*)x)[i + 256], v2 = ((const V*)x)[i + 512], v3 = ((const V*)x)[i + 768];
+        grad(i, v0);
+        grad(i + 256, v1);
+        grad(i + 512, v2);
+        grad(i + 768, v3);
     }
+    for (; i < nvec; i += 256) grad(i, ((const V*)x)[i]);
     for (int i = nvec * VN + threadIdx.x; i < V_; i += 256) {
         float g = __expf((float)x[i] - lse);
         if (i == lab) g -= 1.f;
