@@ -428,11 +428,14 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
 
     v8 qf[C::QT][C::NDC], gf[C::QT][C::NDC];
     float lse2[C::QT], dlt[C::QT];
+    // the row statistics are only LOADED here (clamped address, no select, no scaling): arithmetic right behind the load made
+    // hipcc wait for it before the Q / dO / first K,V tile loads were even issued -- two extra memory round trips per workgroup
+    float lraw[C::QT], draw[C::QT];
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
         const int t = t0 + qt * 16 + x;
-        lse2[qt] = (t < T_) ? lse[(size_t)bh * T_ + t] * LOG2E : 0.f;
-        dlt[qt] = (t < T_) ? delta[(size_t)bh * T_ + t] : 0.f;
+        lraw[qt] = lse[(size_t)bh * T_ + min(t, T_ - 1)];
+        draw[qt] = delta[(size_t)bh * T_ + min(t, T_ - 1)];
 #pragma unroll
         for (int dc = 0; dc < C::NDC; ++dc) {
             qf[qt][dc] = buf_load8<T>(rq, row_off<T, C>(t, rbq, dc * 32 + g * 8));
@@ -448,6 +451,14 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
     TileStage<T, C, C::TIMG, false> stg;
     stg.loadb(rk, rv, rbk, valid + (size_t)b * Tk, 0, Tk);
     stg.store(Kimg(0), Vimg(0), Vld(0));
+#pragma unroll
+    for (int qt = 0; qt < C::QT; ++qt) {
+        const bool in = t0 + qt * 16 + x < T_;
+        lse2[qt] = in ? lraw[qt] * LOG2E : 0.f;
+        dlt[qt] = in ? draw[qt] : 0.f;
+#pragma unroll
+        for (int dc = 0; dc < C::NDC; ++dc) { loaded(qf[qt][dc]); loaded(gf[qt][dc]); }
+    }
     __syncthreads();
     for (int j = 0; j < nkt; ++j) {                           // double-buffered tiles, one barrier each (see selfattn_fwd_kernel)
         const int s0 = j * KT;
@@ -772,10 +783,14 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
 
     v8 kf[NSBW][C::NDC], vf[NSBW][C::NDC];
     float kbias[NSBW];                                // 0 for a real, valid key of this lane's column; -inf otherwise
+    // One wave per SIMD and nothing else to run: every exposed memory round trip of the prologue is idle time.  The key-valid bytes
+    // are only LOADED here and turned into kbias after the first query tiles have been requested too (a compare right behind each
+    // load made hipcc wait -- vmcnt(0) -- four times in a row, each time also for the K / V loads issued in between).
+    uint8_t kvalid[NSBW];
 #pragma unroll
     for (int sbl = 0; sbl < NSBW; ++sbl) {
         const int s = s0 + sbl * 16 + x;
-        kbias[sbl] = (s < Tk && valid[(size_t)b * Tk + min(s, Tk - 1)] != 0) ? 0.f : -INFINITY;
+        kvalid[sbl] = valid[(size_t)b * Tk + min(s, Tk - 1)];
 #pragma unroll
         for (int dc = 0; dc < C::NDC; ++dc) {
             kf[sbl][dc] = buf_load8<T>(rk, row_off<T, C>(s, rbk, dc * 32 + g * 8));
@@ -883,10 +898,15 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
     // (needs the causal select) while some of its rows precede some key of the group
     const int tstart = max(s0 - P, 0) & ~31;
     const int tdiag = s0 + KW - 1 - P;                               // steps with t0 < tdiag are diagonal
+    auto finish_kbias = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int sbl = 0; sbl < NSBW; ++sbl) kbias[sbl] = (s0 + sbl * 16 + x < Tk && kvalid[sbl] != 0) ? 0.f : -INFINITY;
+    };
     if constexpr (!DB) {
         v8 qA[2][C::NDC], gA[2][C::NDC];
         float lA[2][4], dA[2][4];
         request(tstart, qA, gA, lA, dA);
+        finish_kbias();
         for (int t0 = tstart; t0 < T_; t0 += 32) {
             if (t0 < tdiag) step(on_diag(), t0, qA, gA, lA, dA, qA, gA, lA, dA);
             else step(off_diag(), t0, qA, gA, lA, dA, qA, gA, lA, dA);
@@ -895,6 +915,7 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
         v8 qA[2][C::NDC], gA[2][C::NDC], qB[2][C::NDC], gB[2][C::NDC];
         float lA[2][4], dA[2][4], lB[2][4], dB[2][4];
         request(tstart, qA, gA, lA, dA);
+        finish_kbias();
         int t0 = tstart;
         for (; t0 < T_ && t0 < tdiag; t0 += 64) {                    // diagonal steps (two without a prefix, up to three with one)
             step(on_diag(), t0, qA, gA, lA, dA, qB, gB, lB, dB);
