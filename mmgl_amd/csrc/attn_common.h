@@ -207,6 +207,38 @@ template <typename T, typename C> __device__ __forceinline__ uint32_t row_off(in
     return o;
 }
 
+// Batched staging of a [S, D] operand slab into an LDS image: ALL of a thread's 16-byte chunks are requested (branch-free buffer
+// loads: rows past S and padding channels fall outside the descriptor and read as zero) before the first one is written, so a
+// workgroup pays one memory round trip for K, V and the key mask together.  The loop forms above (stage_row_image /
+// stage_rowmajor_image) wait for each chunk before requesting the next: with the run-time trip count hipcc keeps one load in
+// flight, i.e. 8 + 8 serialized round trips for a 64 x 64 bf16 K and V in a one-wave workgroup.  NT = threads per workgroup.
+template <typename T, typename C, int NT> struct ImageStage {
+    typedef typename Elem<T>::v8 v8;
+    static constexpr int TOTAL = C::SPAD * C::CPR, N = (TOTAL + NT - 1) / NT;
+    v8 r[N];
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, uint32_t row_bytes) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const int i = (int)threadIdx.x + n * NT, s_ = i / C::CPR, c = i % C::CPR;
+            r[n] = buf_load8<T>(rs, (i < TOTAL) ? row_off<T, C>(s_, row_bytes, c * 8) : OOB);
+        }
+    }
+    __device__ __forceinline__ void store_row(T* img) const {              // fragment-linear row image (stage_row_image's layout)
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const int i = (int)threadIdx.x + n * NT, s_ = i / C::CPR, c = i % C::CPR;
+            if (i < TOTAL) *(v8*)(img + rf_idx<C>(s_ >> 4, c >> 2, (s_ & 15) + 16 * (c & 3))) = r[n];
+        }
+    }
+    __device__ __forceinline__ void store_rowmajor(T* img) const {         // row-major padded image (stage_rowmajor_image's layout)
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const int i = (int)threadIdx.x + n * NT, s_ = i / C::CPR, c = i % C::CPR;
+            if (i < TOTAL) *(v8*)(img + s_ * C::LD + c * 8) = r[n];
+        }
+    }
+};
+
 // bf16 row-per-lane epilogue: a lane owns 4 consecutive channels (8 B) of each 16-channel block.  Swapping the odd
 // 16-lane rows of block `a` with the even rows of block `b` (= a + 1) leaves every lane with 8 consecutive channels:
 // rows g = 0,2 hold block a's channels 8(g/2)..+7, rows g = 1,3 block b's -- one 16-byte store per lane and 64 contiguous

@@ -85,10 +85,20 @@ __global__ __launch_bounds__(256, MMGL_XATTN_MINWAVES) void xattn_fwd_kernel(con
             qn[qt][dc] = buf_load8<T>(rq, row_off<T, C>((t0 < wg_end) ? t0 + qt * 16 + x : T_, row_bytes, dc * 32 + g * 8));
 
 #if !(MMGL_XATTN_ABLATE & 2)
-    stage_row_image<T, C>(Kf, k + (size_t)b * S * HD + h * D, HD, S);
-    if constexpr (C::TIMG) stage_rowmajor_image<T, C>(Vi, v + (size_t)b * S * HD + h * D, HD, S);
-    else stage_row_image<T, C>(Vi, v + (size_t)b * S * HD + h * D, HD, S);
-    for (int i = threadIdx.x; i < C::SPAD; i += blockDim.x) vld[i] = (i < S) ? valid[(size_t)b * S + i] : 0;
+    {   // K, V and the key mask in ONE memory round trip (ImageStage); the mask byte is only loaded here, its select sits at the store
+        const uint32_t slab_kv = (uint32_t)(((size_t)(S - 1) * HD + D) * sizeof(T));
+        const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * S * HD + h * D, slab_kv);
+        const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * S * HD + h * D, slab_kv);
+        ImageStage<T, C, 256> ks_, vs_;
+        const int vi = min((int)threadIdx.x, C::SPAD - 1);
+        const uint8_t vraw = valid[(size_t)b * S + min(vi, S - 1)];
+        ks_.load(rk, row_bytes);
+        vs_.load(rv, row_bytes);
+        ks_.store_row(Kf);
+        if constexpr (C::TIMG) vs_.store_rowmajor(Vi);
+        else vs_.store_row(Vi);
+        if ((int)threadIdx.x < C::SPAD) vld[threadIdx.x] = (vi < S) ? vraw : (uint8_t)0;
+    }
     __syncthreads();
 #endif
 
@@ -770,9 +780,19 @@ __global__ __launch_bounds__(64) void xattn_bwd_fused_kernel(const bf16* __restr
     request(row_begin, qA, gA, lA);
     request(row_begin + 32, qB, gB, lB);
 
-    stage_rowmajor_image<T, C>(Ki, k + (size_t)b * S * HD + h * D, HD, S);
-    stage_row_image<T, C>(Vf, v + (size_t)b * S * HD + h * D, HD, S);
-    for (int i = lane; i < C::SPAD; i += 64) vld[i] = (i < S) ? valid[(size_t)b * S + i] : 0;
+    {   // K, V and the key mask in ONE memory round trip (ImageStage: a one-wave workgroup has nothing else to hide 17 of them)
+        static_assert(C::SPAD <= 64, "fused backward: one mask byte per lane");
+        const uint32_t slab_kv = (uint32_t)(((size_t)(S - 1) * HD + D) * sizeof(T));
+        const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * S * HD + h * D, slab_kv);
+        const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * S * HD + h * D, slab_kv);
+        ImageStage<T, C, 64> ks_, vs_;
+        const uint8_t vraw = valid[(size_t)b * S + min(lane, S - 1)];
+        ks_.load(rk, row_bytes);
+        vs_.load(rv, row_bytes);
+        ks_.store_rowmajor(Ki);
+        vs_.store_row(Vf);
+        if (lane < C::SPAD) vld[lane] = (lane < S) ? vraw : (uint8_t)0;
+    }
     __syncthreads();
 
     uint32_t vlo, vhi, elo, ehi;
