@@ -747,6 +747,20 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
 // NSBW = 16-key blocks per wave: 4 (64 keys) up to D = 64, 2 (32 keys) at D = 128 (the dK / dV accumulators are NSBW * D / 4 registers each)
 // DB: two register sets for the Q / dO rows (the next tile in flight during this one: what a lone wave per SIMD needs); false:
 // one set, re-requested at the end of the step -- fits two waves per SIMD at 32 keys per wave, which then hide each other's latency
+#ifndef SA_DKV_AGPR
+#define SA_DKV_AGPR 0
+#endif
+// Experiment, off: dK / dV accumulators in AGPRs.  The file is built with MFMA results in plain VGPRs (the softmax arithmetic works
+// on every S / dP accumulator), which leaves this kernel's 128 dK / dV accumulator registers -- touched by nothing but MFMAs until
+// the end -- in VGPRs too and pushes Q / dO prefetch data out into AGPRs: 209 of the 809 instructions of a 64-row step are
+// v_accvgpr_read / write / mov copies.  An inline-asm MFMA with a "+a" accumulator pins them where they belong: 24 copies, 619
+// instructions -- and the same 950 us per backward (B = 64): with one wave per SIMD the step is bound by its dependency chain
+// (tile write -> transpose reads -> S / dP -> exp -> dV / dK), not by issue slots.  Left off: no gain, and the hazard recognizer
+// does not see inline-asm MFMAs.
+__device__ __forceinline__ void mma16_agpr(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
 template <int D, int NSBW, bool DB = true>
 __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ q,
                                                                 const bf16* __restrict__ k, const bf16* __restrict__ v,
@@ -885,8 +899,13 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
             const v8 pB = pack8<T>(pr[0], pr[1]), dsB = pack8<T>(dsr[0], dsr[1]);
 #pragma unroll
             for (int db = 0; db < C::NDB; ++db) {
+#if SA_DKV_AGPR
+                mma16_agpr(dva[db][sbl], gT[db], pB);
+                mma16_agpr(dka[db][sbl], qT[db], dsB);
+#else
                 mma16(dva[db][sbl], gT[db], pB);
                 mma16(dka[db][sbl], qT[db], dsB);
+#endif
             }
         }
         if constexpr (!DB) request(t0 + 32, qn, gn, ln, dn);         // qn aliases qa: its last reader has been issued
@@ -926,6 +945,9 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
             if (t0 + 32 < T_) step(off_diag(), t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
         }
     }
+#if SA_DKV_AGPR
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last inline-asm MFMAs' results: the hazard recognizer does not see them
+#endif
 #pragma unroll
     for (int sbl = 0; sbl < NSBW; ++sbl) {
         const int s = s0 + sbl * 16 + x;
