@@ -77,7 +77,11 @@ __device__ __forceinline__ void online_softmax_row(f32x4 (&s)[4], float& m, f32x
 // "These registers are complete": an empty asm that reads them, placed ahead of a loop.  A load issued before a loop and first used
 // inside it stays pending in hipcc's waitcnt scoreboard at the loop header, so every iteration waits with a count that means
 // "the prefetch I just issued as well" -- the next tile's loads drained in the middle of the current tile's MFMAs.
-template <typename V> __device__ __forceinline__ void loaded(const V& v) { asm volatile("" ::"v"(v)); }
+template <typename V> __device__ __forceinline__ void loaded(const V& v) {
+#if defined(__HIP_DEVICE_COMPILE__)          // (the host pass would check the "v" constraint against x86 register classes)
+    asm volatile("" ::"v"(v));
+#endif
+}
 
 template <typename T, typename C, bool K_ROWMAJOR, bool V_ROWMAJOR> struct TileStage {
     typedef typename Elem<T>::v8 v8;
@@ -758,7 +762,9 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
 // (tile write -> transpose reads -> S / dP -> exp -> dV / dK), not by issue slots.  Left off: no gain, and the hazard recognizer
 // does not see inline-asm MFMAs.
 __device__ __forceinline__ void mma16_agpr(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#endif
 }
 
 template <int D, int NSBW, bool DB = true>
@@ -795,6 +801,7 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(delta + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
 
+    [[maybe_unused]] const int tstart0 = max(s0 - P, 0) & ~31;
     v8 kf[NSBW][C::NDC], vf[NSBW][C::NDC];
     float kbias[NSBW];                                // 0 for a real, valid key of this lane's column; -inf otherwise
     // One wave per SIMD and nothing else to run: every exposed memory round trip of the prologue is idle time.  The key-valid bytes
@@ -818,6 +825,9 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
         for (int sbl = 0; sbl < NSBW; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
 
     auto request = [&](int tbase, v8 (&qn)[2][C::NDC], v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
+#if SA_ABLATE & 4                           // timing experiment: the query tiles are fetched once (results are wrong)
+        if (tbase > tstart0 + 32) return;
+#endif
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
 #pragma unroll
