@@ -758,9 +758,9 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
 // on every S / dP accumulator), which leaves this kernel's 128 dK / dV accumulator registers -- touched by nothing but MFMAs until
 // the end -- in VGPRs too and pushes Q / dO prefetch data out into AGPRs: 209 of the 809 instructions of a 64-row step are
 // v_accvgpr_read / write / mov copies.  An inline-asm MFMA with a "+a" accumulator pins them where they belong: 24 copies, 619
-// instructions -- and the same 950 us per backward (B = 64): with one wave per SIMD the step is bound by its dependency chain
-// (tile write -> transpose reads -> S / dP -> exp -> dV / dK), not by issue slots.  Left off: no gain, and the hazard recognizer
-// does not see inline-asm MFMAs.
+// instructions -- for 920 -> 905 us per backward (B = 64) and a FAILING parity test: the hazard recognizer does not see inline-asm
+// MFMAs.  With one wave per SIMD the step is bound by its dependency chain (tile write -> transpose reads -> S / dP -> exp ->
+// dV / dK), not by issue slots (query tiles fetched only once, -DSA_ABLATE=4: 920 -> 870 us, so memory latency is not it either).
 __device__ __forceinline__ void mma16_agpr(f32x4& acc, const bf16x8& a, const bf16x8& b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
