@@ -29,6 +29,18 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert _lib.lib().mmgl_version() >= 100
 
 
+def test_library_is_not_older_than_its_sources():
+    """A failed compile leaves the previous libmmgl_hip.so in place and every later run silently measures old code (it happened:
+    an inline-asm constraint the HOST pass rejected).  The library must be newer than every kernel source and header."""
+    import glob
+    from mmgl_amd import _lib
+    srcs = glob.glob(os.path.join(ROOT, "mmgl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mmgl_amd", "csrc", "*.h")) \
+        + [os.path.join(ROOT, "include", "mmgl_hip.h")]
+    newest = max(srcs, key=os.path.getmtime)
+    assert os.path.getmtime(_lib.LIB_PATH) >= os.path.getmtime(newest), \
+        f"{_lib.LIB_PATH} is older than {newest}: run `python -m mmgl_amd._build` and read its output"
+
+
 def test_argument_validation_error_codes():
     from mmgl_amd import _lib
     L = _lib.lib()
