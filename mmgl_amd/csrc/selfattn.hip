@@ -1037,9 +1037,14 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
                     typedef XC<bf16, D, 2> C2;
                     const int nkb32 = cdiv(T_ + P, 32);
                     const size_t lds32 = sizeof(bf16) * 2 * 32 * (C2::DPAD + 16);
-                    hipLaunchKernelGGL((selfattn_bwd_dkv64_kernel<D, 2, false>), dim3(B * H * nkb32), dim3(64), lds32, st, (const bf16*)dout,
-                                       (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, (bf16*)dk, (bf16*)dv, B, H, T_,
-                                       nkb32, ldq, ldgk, P, ldk);
+                    if (occ2 == 2)                           // ... with the two-tile register pipeline as well
+                        hipLaunchKernelGGL((selfattn_bwd_dkv64_kernel<D, 2, true>), dim3(B * H * nkb32), dim3(64), lds32, st, (const bf16*)dout,
+                                           (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, (bf16*)dk, (bf16*)dv, B, H, T_,
+                                           nkb32, ldq, ldgk, P, ldk);
+                    else
+                        hipLaunchKernelGGL((selfattn_bwd_dkv64_kernel<D, 2, false>), dim3(B * H * nkb32), dim3(64), lds32, st, (const bf16*)dout,
+                                           (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, (bf16*)dk, (bf16*)dv, B, H, T_,
+                                           nkb32, ldq, ldgk, P, ldk);
                     MMGL_CHECK_LAUNCH("selfattn_bwd_dkv32");
                     return MMGL_OK;
                 }
