@@ -1183,10 +1183,9 @@ int linear_bwd(const T* dy, const T* y, const T* x, const T* W, T* dx, T* dW, T*
                 T* Wt = (T*)(ws + bf16_wt_offset(M, N, act));
                 rc = launch_transpose<T>(W, nullptr, Wt, nullptr, N, K, 1.f, 0, st);
                 bool masked = false;
-                if (!rc && tune_gemm_8p() && gemm8p_supported(M, K, N, N, N, K) && cdiv(M, 256) * cdiv(K, 256) < tune_gemm_8p_min_tiles() &&
-                    gemm8p_use_splits(M, K, N)) {
-                    // few tiles (the reference's batch): K-split work items, partial tiles in the region the weight gradient's
-                    // split partials use afterwards (same stream: the dgrad has consumed them by then)
+                if (!rc && tune_gemm_8p() && gemm8p_supported(M, K, N, N, N, K) && gemm8p_use_splits(M, K, N)) {
+                    // few tiles, or a remainder of a round of tiles (the reference's batch): K-split work items, scratch tiles in
+                    // the region the weight gradient's split partials use afterwards (same stream: the dgrad has consumed them by then)
                     rc = launch_gemm8p((const bf16*)a, N, (const bf16*)Wt, N, (bf16*)dx, K, nullptr, nullptr, mask_dx ? (const bf16*)x : nullptr,
                                        M, K, N, MMGL_ACT_NONE, sc, st, (float*)(ws + bf16_part_offset(M, N, K, act)), gemm8p_split_bytes(M, K, N));
                     masked = mask_dx;
@@ -1280,7 +1279,7 @@ extern "C" int mmgl_gemm_nt_fast(int M, int N, int K, int ldx, int ldw, int ldy,
 
 extern "C" size_t mmgl_gemm_nt_workspace(int M, int N, int K, int ldx, int ldw, int ldy, int dtype) {
     if (dtype != MMGL_BF16 || !tune_gemm_8p() || !gemm8p_supported(M, N, K, ldx, ldw, ldy)) return 0;
-    if (cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles() || !gemm8p_use_splits(M, N, K)) return 0;
+    if (!gemm8p_use_splits(M, N, K)) return 0;              // few-tile outputs and remainders of a round of tiles (gemm8p_plan)
     return align_up(gemm8p_split_bytes(M, N, K), 256);
 }
 

@@ -54,6 +54,7 @@ struct P8Args {
     int tiles_m, tiles_n, total;
     int nsplit;            // K splits per output tile (1 = none): work item = (tile, split), fp32 partial tiles into `part`
     float* part;           // [nsplit][M][N] fp32 (ACT = 5 kernels)
+    int tile0;             // first output tile of this launch (a hybrid launch: full tiles first, the rest as K-split items)
     int stagger;           // start delay per CU group in units of 256 clocks (0 = none)
     int stag_mask;         // CU groups - 1 (power of two; group = CU index within its XCD & mask)
     long long* trace;      // timing experiments only (P8_TRACE builds): [8 waves][64] clock stamps of workgroup trace_wg
@@ -136,7 +137,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         if (v >= a.total * a.nsplit) return false;
         int tm, tn;
         sp = v % a.nsplit;
-        grouped_tile(v / a.nsplit, a.tiles_m, a.tiles_n, tm, tn);
+        grouped_tile(a.tile0 + v / a.nsplit, a.tiles_m, a.tiles_n, tm, tn);
         m0 = tm * 256;
         n0 = tn * 256;
         const int units = a.K >> 7, base = units / a.nsplit, rem = units % a.nsplit;
@@ -256,23 +257,22 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     // the tile up front: one exposed memory latency per tile instead of one per quadrant.
     auto epilogue_q = [&](int m0, int n0, int par, int q_lo, int q_hi) __attribute__((always_inline)) {
         if constexpr (ACT == 5) {
-            // K-split work item: the raw fp32 accumulators of this split go to part[sp][m][n]; bias / activation / masks are
-            // applied by p8_splitk_finish_kernel when it folds the splits
+            // K-split work item: the raw fp32 accumulators of this split go to its own 256 x 256 fp32 scratch tile,
+            // part[(tile - tile0) * nsplit + split][256][256] (whole tiles: no bounds to check); bias / activation / masks are applied
+            // by p8_splitk_finish_kernel when it folds the splits
             const int ln = p8_lane();
             const int ncol_l = wc * 64 + 8 * (ln >> 4);
-            const bool ok0 = n0 + ncol_l < a.N, ok1 = n0 + ncol_l + 32 < a.N;
-            const unsigned base = (unsigned)(((wr * 128 + (ln & 15)) * a.N + n0 + ncol_l) * 4);
-            const unsigned rstep = (unsigned)(16 * a.N * 4);
-            long long rem = (long long)(a.M - m0) * a.N * 4;
-            if (rem > 0xffffffffLL) rem = 0xffffffffLL;
-            const __amdgpu_buffer_rsrc_t dP = __builtin_amdgcn_make_buffer_rsrc((void*)(a.part + ((size_t)sp0 * a.M + m0) * a.N), 0, (int)(unsigned)rem, 0x00020000);
+            const unsigned base = (unsigned)(((wr * 128 + (ln & 15)) * 256 + ncol_l) * 4);
+            const unsigned rstep = (unsigned)(16 * 256 * 4);
+            const int vitem = par * G + wg;                                  // = (tile - tile0) * nsplit + split
+            const __amdgpu_buffer_rsrc_t dP = __builtin_amdgcn_make_buffer_rsrc((void*)(a.part + ((size_t)vitem << 16)), 0, 256 * 256 * 4, 0x00020000);
 #pragma unroll
             for (int T0 = 0; T0 < 4; T0 += 2)
 #pragma unroll
                 for (int J = 0; J < 8; ++J) {
-                    const unsigned off = (T0 ? ok1 : ok0) ? base + (unsigned)J * rstep + (unsigned)(64 * T0) : 0xffffffffu;
+                    const unsigned off = base + (unsigned)J * rstep + (unsigned)(64 * T0);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, acc[T0][J]), dP, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, acc[T0 + 1][J]), dP, off == 0xffffffffu ? off : off + 16, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, acc[T0 + 1][J]), dP, off + 16, 0, 0);
                     acc[T0][J] = vzero<f32x4>();
                     acc[T0 + 1][J] = vzero<f32x4>();
                 }
@@ -553,16 +553,21 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
 // fold the K splits of ACT = 5 work items and apply the epilogue:  Y = act((sum_s part[s] + bias) * scale) (zmask, + resid)
 __global__ __launch_bounds__(256) void p8_splitk_finish_kernel(const float* __restrict__ part, bf16* __restrict__ Y, const bf16* __restrict__ bias,
                                                                const bf16* __restrict__ resid, const bf16* __restrict__ zmask, int M, int N, int ldy,
-                                                               int nsplit, int act, float scale) {
-    const size_t nv = (size_t)M * (N / 8), plane = (size_t)M * N;
+                                                               int nsplit, int act, float scale, int tile0, int ntiles, int tiles_m, int tiles_n) {
+    // one 8-column vector per thread and trip: tile (i >> 13), row (i >> 5) & 255, columns 8 (i & 31) of the split tiles' scratch
+    const size_t nv = (size_t)ntiles << 13;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
-        const size_t m = i / (N / 8);
-        const int n = (int)(i - m * (N / 8)) * 8;
-        const float* p = part + m * N + n;
+        const int tl = (int)(i >> 13), r = (int)(i >> 5) & 255, c8 = ((int)i & 31) * 8;
+        int tm, tn;
+        grouped_tile(tile0 + tl, tiles_m, tiles_n, tm, tn);
+        const size_t m = (size_t)tm * 256 + r;
+        const int n = tn * 256 + c8;
+        if (m >= (size_t)M || n >= N) continue;
+        const float* p = part + (((size_t)tl * nsplit) << 16) + r * 256 + c8;
         f32x4 lo = *(const f32x4*)p, hi = *(const f32x4*)(p + 4);
         for (int sp = 1; sp < nsplit; ++sp) {
-            lo += *(const f32x4*)(p + sp * plane);
-            hi += *(const f32x4*)(p + sp * plane + 4);
+            lo += *(const f32x4*)(p + ((size_t)sp << 16));
+            hi += *(const f32x4*)(p + ((size_t)sp << 16) + 4);
         }
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         if (bias) {
@@ -600,15 +605,47 @@ __global__ __launch_bounds__(256) void p8_splitk_finish_kernel(const float* __re
 
 }  // namespace
 
-// K splits for an output with too few 256x256 tiles to fill the chip (0 = none): about one work item per CU, each at least
-// two 128-wide K steps.  N % 8 == 0 is implied by gemm8p_supported.
-int gemm8p_splits(int M, int N, int K) {
+// Work plan of one GEMM: tiles [0, direct) run as whole 256x256 output tiles, tiles [direct, total) as nsplit K-split work items
+// each (fp32 scratch tiles, folded by p8_splitk_finish_kernel).  Two cases split:
+//  * an output with too few tiles to fill the chip (direct = 0): about one work item per CU, each at least two 128-wide K steps;
+//    measured: a gain from K = 3072 up (K = 8192: 129 -> 92 us at M = 2560), a loss at K <= 2048;
+//  * an output of one to three rounds of tiles plus a remainder of at most half a round (the reference's batch: 2560 x 8192 =
+//    320 tiles on 256 CUs): the remainder would occupy a quarter of the chip for a whole tile time; cut into K splits it takes a
+//    quarter of that.
+// N % 8 == 0 is implied by gemm8p_supported.
+static int p8_num_cu() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    return n;
+}
+void gemm8p_plan(int M, int N, int K, int* direct, int* nsplit) {
     const int tiles = cdiv(M, 256) * cdiv(N, 256), units = K / 128;
-    if (tiles >= 160 || units < 24) return 0;          // measured: a gain from K = 3072 up (K = 8192: 129 -> 92 us at M = 2560), a loss at K <= 2048
-    int s = (224 + tiles - 1) / tiles;
+    *direct = tiles;
+    *nsplit = 0;
+    if (tiles < 160) {
+        if (units < 24) return;
+        int s = (224 + tiles - 1) / tiles;
+        if (s > 8) s = 8;
+        if (s > units / 2) s = units / 2;
+        if (s >= 2) { *direct = 0; *nsplit = s; }
+        return;
+    }
+    static const int hybrid = [] { const char* e = getenv("MMGL_GEMM_8P_HYBRID"); return e ? atoi(e) : 3; }();   // smallest split count worth it (0 = off)
+    const int G = p8_num_cu(), rounds = tiles / G, r = tiles % G;
+    if (!hybrid || rounds < 1 || rounds > 3 || r == 0) return;
+    int s = G / r;
     if (s > 8) s = 8;
-    if (s > units / 2) s = units / 2;
-    return s >= 2 ? s : 0;
+    if (s > units / 4) s = units / 4;                     // at least four 128-wide K steps per item
+    if (s >= hybrid && s >= 2) { *direct = tiles - r; *nsplit = s; }
+}
+int gemm8p_splits(int M, int N, int K) {
+    int d, s;
+    gemm8p_plan(M, N, K, &d, &s);
+    return s;
 }
 
 bool gemm8p_supported(int M, int N, int K, int ldx, int ldw, int ldy) {
@@ -616,7 +653,11 @@ bool gemm8p_supported(int M, int N, int K, int ldx, int ldw, int ldy) {
            (long long)M * ldx * 2 < 0xffffffffLL && (long long)N * ldw * 2 < 0xffffffffLL;
 }
 
-size_t gemm8p_split_bytes(int M, int N, int K) { return (size_t)gemm8p_splits(M, N, K) * M * N * sizeof(float); }
+size_t gemm8p_split_bytes(int M, int N, int K) {
+    int d, sp;
+    gemm8p_plan(M, N, K, &d, &sp);
+    return sp ? (size_t)(cdiv(M, 256) * cdiv(N, 256) - d) * sp * (256 * 256 * sizeof(float)) : 0;
+}
 
 int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, const bf16* resid,
                   const bf16* zmask, int M, int N, int K, int act, float scale, hipStream_t st, float* part, size_t part_bytes) {
@@ -643,50 +684,62 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
             if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
     }
-    // few-tile outputs (the reference's batch of 4: M = 2560): K-split work items with fp32 partial tiles in the CALLER's scratch
-    // (gemm8p_split_bytes), folded -- with the whole epilogue -- by p8_splitk_finish_kernel.  Without scratch the tile is not split.
-    const int nsplit = (part && part_bytes >= gemm8p_split_bytes(M, N, K)) ? gemm8p_splits(M, N, K) : 0;
+    // the work plan (gemm8p_plan): whole tiles [0, direct), then K-split work items for the rest with fp32 scratch tiles in the
+    // CALLER's memory (gemm8p_split_bytes), folded -- with the whole epilogue -- by p8_splitk_finish_kernel.  Without scratch
+    // nothing is split.
+    const int tiles = a.total;
+    int direct = tiles, nsplit = 0;
+    if (part && part_bytes >= gemm8p_split_bytes(M, N, K)) gemm8p_plan(M, N, K, &direct, &nsplit);
+    a.trace = nullptr;
+    a.trace_wg = 0;
+    a.stagger = 0;
+    a.stag_mask = 0;
+    a.tile0 = 0;
+    if (direct > 0) {
+        a.total = direct;
+        const int grid = direct < n_cu ? direct : n_cu;
+        // MMGL_GEMM_STAGGER = start offset between CU groups in clocks, MMGL_GEMM_STAGGER_GROUPS = 2 / 4 / 8 / 16 / 32 groups
+        static const int stag_clk = [] { const char* e = getenv("MMGL_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+        static const int stag_grp = [] { const char* e = getenv("MMGL_GEMM_STAGGER_GROUPS"); const int g = e ? atoi(e) : 4;
+                                         return (g >= 2 && g <= 32 && !(g & (g - 1))) ? g : 4; }();
+        static const int stag_rounds = [] { const char* e = getenv("MMGL_GEMM_STAGGER_ROUNDS"); return e ? atoi(e) : 2; }();
+        a.stagger = (stag_clk > 0 && a.total >= stag_rounds * grid) ? (stag_clk + 128) / 256 : 0;
+        a.stag_mask = stag_grp - 1;
+#if P8_TRACE
+        if (const char* e = getenv("MMGL_P8_TRACE")) a.trace = (long long*)strtoull(e, nullptr, 0);
+        if (const char* e = getenv("MMGL_P8_TRACE_WG")) a.trace_wg = atoi(e);
+#endif
+        const bool zr = resid || zmask;
+#define P8_LAUNCH(A, Z) hipLaunchKernelGGL((gemm8p_kernel<A, Z>), dim3(grid), dim3(512), P8_LDS_TOTAL, st, a)
+        switch (act) {
+            case 0: if (zr) P8_LAUNCH(0, true); else P8_LAUNCH(0, false); break;
+            case 1: if (zr) P8_LAUNCH(1, true); else P8_LAUNCH(1, false); break;
+            case 2: if (zr) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm8p: gelu(erf) with residual / zmask is not instantiated"); P8_LAUNCH(2, false); break;
+            case 3: if (zr) P8_LAUNCH(3, true); else P8_LAUNCH(3, false); break;
+            case 4: P8_LAUNCH(4, true); break;
+            default: MMGL_FAIL(MMGL_ERR_INVALID, "gemm8p: unknown activation %d", act);
+        }
+#undef P8_LAUNCH
+        MMGL_CHECK_LAUNCH("gemm8p");
+    }
     if (nsplit) {
+        MMGL_CHECK_ARG(act >= 0 && act <= 4, "gemm8p: unknown activation %d", act);
+        const int rest = tiles - direct;
+        a.tile0 = direct;
+        a.total = rest;
         a.nsplit = nsplit;
         a.part = part;
-        const int items = a.total * nsplit, g = items < n_cu ? items : n_cu;
         a.stagger = 0;
         a.stag_mask = 0;
         a.trace = nullptr;
+        const int items = rest * nsplit, g = items < n_cu ? items : n_cu;
         hipLaunchKernelGGL((gemm8p_kernel<5, false>), dim3(g), dim3(512), P8_LDS_TOTAL, st, a);
         MMGL_CHECK_LAUNCH("gemm8p (K split)");
-        const size_t nv = (size_t)M * (N / 8);
-        int blocks = (int)((nv + 255) / 256);
+        int blocks = rest * 32;                                  // 8192 vectors per tile, 256 per block and trip
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(p8_splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, part, Y, bias, resid, zmask, M, N, ldy, nsplit, act, scale);
+        hipLaunchKernelGGL(p8_splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, part, Y, bias, resid, zmask, M, N, ldy, nsplit, act, scale,
+                           direct, rest, a.tiles_m, a.tiles_n);
         MMGL_CHECK_LAUNCH("gemm8p split-K finish");
-        return MMGL_OK;
     }
-    const int grid = a.total < n_cu ? a.total : n_cu;
-    // MMGL_GEMM_STAGGER = start offset between CU groups in clocks, MMGL_GEMM_STAGGER_GROUPS = 2 / 4 / 8 / 16 / 32 groups
-    static const int stag_clk = [] { const char* e = getenv("MMGL_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
-    static const int stag_grp = [] { const char* e = getenv("MMGL_GEMM_STAGGER_GROUPS"); const int g = e ? atoi(e) : 4;
-                                     return (g >= 2 && g <= 32 && !(g & (g - 1))) ? g : 4; }();
-    static const int stag_rounds = [] { const char* e = getenv("MMGL_GEMM_STAGGER_ROUNDS"); return e ? atoi(e) : 2; }();
-    a.stagger = (stag_clk > 0 && a.total >= stag_rounds * grid) ? (stag_clk + 128) / 256 : 0;
-    a.stag_mask = stag_grp - 1;
-    a.trace = nullptr;
-    a.trace_wg = 0;
-#if P8_TRACE
-    if (const char* e = getenv("MMGL_P8_TRACE")) a.trace = (long long*)strtoull(e, nullptr, 0);
-    if (const char* e = getenv("MMGL_P8_TRACE_WG")) a.trace_wg = atoi(e);
-#endif
-    const bool zr = resid || zmask;
-#define P8_LAUNCH(A, Z) hipLaunchKernelGGL((gemm8p_kernel<A, Z>), dim3(grid), dim3(512), P8_LDS_TOTAL, st, a)
-    switch (act) {
-        case 0: if (zr) P8_LAUNCH(0, true); else P8_LAUNCH(0, false); break;
-        case 1: if (zr) P8_LAUNCH(1, true); else P8_LAUNCH(1, false); break;
-        case 2: if (zr) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm8p: gelu(erf) with residual / zmask is not instantiated"); P8_LAUNCH(2, false); break;
-        case 3: if (zr) P8_LAUNCH(3, true); else P8_LAUNCH(3, false); break;
-        case 4: P8_LAUNCH(4, true); break;
-        default: MMGL_FAIL(MMGL_ERR_INVALID, "gemm8p: unknown activation %d", act);
-    }
-#undef P8_LAUNCH
-    MMGL_CHECK_LAUNCH("gemm8p");
     return MMGL_OK;
 }

@@ -44,6 +44,9 @@ CASES = [
     (2560, 2048, 8192, 1, True, False, False, 1.0),      # the reference's batch of 4 (80 tiles): K-split work items + finish kernel
     (2600, 2048, 6144, 3, True, True, False, 0.5),       # uneven K splits (48 steps over 3), ragged M, residual, scale
     (2560, 2064, 3072, 0, False, False, True, 1.0),      # K split with a ragged last column tile and the zmask applied by the finish kernel
+    (2560, 8192, 2048, 1, True, False, False, 1.0),      # 320 tiles on 256 CUs: one round of whole tiles + the other 64 as 4 K-split items each
+    (2570, 8200, 2048, 0, True, True, True, 0.5),        # the same with ragged last tile row / column (363 tiles), zmask + residual in the finish kernel
+    (2560, 8192, 4096, 3, False, False, False, 1.0),     # hybrid plan, 8-way remainder capped by its K steps
     (1024, 512, 256, 1, True, False, False, 1.0),        # small: composed path (128x128 kernel + elementwise)
     (300, 96, 64, 2, True, True, True, 2.0),             # tiny, ragged K tile: composed path
 ]
