@@ -252,7 +252,8 @@ int mmgl_adamw_step(void* param, float* master, const void* grad, float* exp_avg
  * mmgl_relu_bwd: out = dy * (y > 0), the backward of a stand-alone ReLU epilogue (in place allowed). */
 int mmgl_gemm_nt_fast(int M, int N, int K, int ldx, int ldw, int ldy, int dtype);
 /* workspace: shapes with fewer 256x256 output tiles than the chip has CUs and a long contraction (the reference's batch of 4:
- * M = 2560, K >= 3072) are cut into K-split work items whose fp32 partial tiles live in caller memory, like every other
+ * M = 2560, K >= 3072), and the last partial round of tiles of a one-to-three-round output (2560 x 8192: 320 tiles on 256 CUs),
+ * are cut into K-split work items whose fp32 partial tiles live in caller memory, like every other
  * scratch of this library (no allocation inside).  mmgl_gemm_nt_workspace returns the bytes that takes (0 for every other
  * shape); with workspace == NULL or fewer bytes the same kernel runs unsplit (same result up to fp32 summation order). */
 size_t mmgl_gemm_nt_workspace(int M, int N, int K, int ldx, int ldw, int ldy, int dtype);
