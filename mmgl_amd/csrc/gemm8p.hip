@@ -98,6 +98,14 @@ __device__ __forceinline__ int p8_lane() {
 #ifndef P8_REALIGN
 #define P8_REALIGN 1                 // one extra barrier per wave group and tile: both groups' epilogues between the same two barriers
 #endif
+// Cache policy bits of the output stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  nt + sc1: the output tile is streamed out without
+// staying in the L2 that holds the operand tiles the other workgroups of the XCD are about to read -- 40960x8192x2048 1029 -> 920 us
+// (1336 -> 1494 TF), 6144 columns 754 -> 706, 2048 columns 269 -> 253, the seven shapes of tools/probes/gemm_stagger.py 3494 -> 3299 us;
+// in the training step (whose next kernel reads that output) 256.3 -> 259.8 samples/s.  0 / 1 / 16 / 17: no change; 2 / 3: as 18 but
+// 2 % behind on the K = 768 shape.
+#ifndef P8_STORE_AUX
+#define P8_STORE_AUX 18
+#endif
 #ifndef P8_TRACE
 #define P8_TRACE 0                   // timing experiments only: clock stamps of workgroup 0 into P8Args::trace
 #endif
@@ -358,7 +366,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
 #if P8_ABLATE & 2
                     asm volatile("" :: "v"(ob));
 #else
-                    __builtin_amdgcn_raw_buffer_store_b128(ob, dY, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ob, dY, off, 0, P8_STORE_AUX);
 #endif
                 }
             };
