@@ -165,6 +165,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
+#ifndef ATTN_STORE_AUX
+#define ATTN_STORE_AUX 0         // cache policy bits of the attention kernels' output stores (2 = nt, 16 = sc1): timing experiments
+#endif
 #define OOB 0x80000000u          // byte offset past any descriptor range (< 2 GiB), with room for +offsets without wrapping: loads return 0, stores are dropped
 
 // Hardware-bounds-checked buffer access: rows past T (and the zero-padded channels of D = 16) need no branches, so the
@@ -185,20 +188,20 @@ template <> __device__ __forceinline__ f32x8 buf_load8<float>(__amdgpu_buffer_rs
 }
 template <typename T> __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, uint32_t off, const f32x4& v);
 template <> __device__ __forceinline__ void buf_store4<bf16>(__amdgpu_buffer_rsrc_t r, uint32_t off, const f32x4& v) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4)), r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4)), r, off, 0, ATTN_STORE_AUX);
 }
 template <> __device__ __forceinline__ void buf_store4<float>(__amdgpu_buffer_rsrc_t r, uint32_t off, const f32x4& v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, ATTN_STORE_AUX);
 }
 template <typename T> __device__ __forceinline__ typename Elem<T>::v4 cvt4(const f32x4& v);
 template <> __device__ __forceinline__ f32x4 cvt4<float>(const f32x4& v) { return v; }
 template <> __device__ __forceinline__ bf16x4 cvt4<bf16>(const f32x4& v) { return __builtin_convertvector(v, bf16x4); }
 template <typename T> __device__ __forceinline__ void buf_store_v4(__amdgpu_buffer_rsrc_t r, uint32_t off, const typename Elem<T>::v4& v);
 template <> __device__ __forceinline__ void buf_store_v4<bf16>(__amdgpu_buffer_rsrc_t r, uint32_t off, const bf16x4& v) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0, ATTN_STORE_AUX);
 }
 template <> __device__ __forceinline__ void buf_store_v4<float>(__amdgpu_buffer_rsrc_t r, uint32_t off, const f32x4& v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, ATTN_STORE_AUX);
 }
 // byte offset of (row t, channel dcol) in a [T, H*D] slab whose descriptor starts at (b, 0, h*D); OOB for padding channels
 template <typename T, typename C> __device__ __forceinline__ uint32_t row_off(int t, uint32_t row_bytes, int dcol) {
@@ -253,7 +256,7 @@ __device__ __forceinline__ void store_pair_bf16(__amdgpu_buffer_rsrc_t r, uint32
     swap16_u32(a1, b1);
     const u32x4 v = {a0, a1, b0, b1};
     const uint32_t off = row_byte_off + (uint32_t)((blk_a + (g & 1)) * 32 + (g >> 1) * 16);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, ATTN_STORE_AUX);
 }
 
 // reductions across the four 16-lane groups that share a query row: v_permlane16_swap / v_permlane32_swap are plain
