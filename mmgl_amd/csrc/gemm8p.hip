@@ -106,6 +106,12 @@ __device__ __forceinline__ int p8_lane() {
 #ifndef P8_STORE_AUX
 #define P8_STORE_AUX 18
 #endif
+#ifndef P8_LOADX_AUX
+#define P8_LOADX_AUX 0               // cache policy bits of the operand streams (timing experiments)
+#endif
+#ifndef P8_LOADW_AUX
+#define P8_LOADW_AUX 0
+#endif
 #ifndef P8_TRACE
 #define P8_TRACE 0                   // timing experiments only: clock stamps of workgroup 0 into P8Args::trace
 #endif
@@ -180,9 +186,14 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         }
     auto stage = [&](int ty, int slot, __amdgpu_buffer_rsrc_t rs, int kbyte) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + slot * P8_UNIT + (wave + 8 * i) * 1024), 16, voff[ty][i],
-                                                     kbyte, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            if (ty & 1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + slot * P8_UNIT + (wave + 8 * i) * 1024), 16, voff[ty][i],
+                                                         kbyte, 0, P8_LOADW_AUX);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + slot * P8_UNIT + (wave + 8 * i) * 1024), 16, voff[ty][i],
+                                                         kbyte, 0, P8_LOADX_AUX);
+        }
     };
 
     // ---- fragment addressing: row x of a 16-row block, k slot (ks * 4 + g) ^ key
