@@ -106,6 +106,9 @@ __device__ __forceinline__ int p8_lane() {
 #ifndef P8_STORE_AUX
 #define P8_STORE_AUX 18
 #endif
+#ifndef P8_PART_AUX
+#define P8_PART_AUX 0                // ... of the K-split scratch tiles (read back by the finish kernel right away)
+#endif
 #ifndef P8_LOADX_AUX
 #define P8_LOADX_AUX 0               // cache policy bits of the operand streams (timing experiments)
 #endif
@@ -290,8 +293,8 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
 #pragma unroll
                 for (int J = 0; J < 8; ++J) {
                     const unsigned off = base + (unsigned)J * rstep + (unsigned)(64 * T0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, acc[T0][J]), dP, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, acc[T0 + 1][J]), dP, off + 16, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, acc[T0][J]), dP, off, 0, P8_PART_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, acc[T0 + 1][J]), dP, off + 16, 0, P8_PART_AUX);
                     acc[T0][J] = vzero<f32x4>();
                     acc[T0 + 1][J] = vzero<f32x4>();
                 }
@@ -646,7 +649,8 @@ void gemm8p_plan(int M, int N, int K, int* direct, int* nsplit) {
     *direct = tiles;
     *nsplit = 0;
     if (tiles < 160) {
-        if (units < 24) return;
+        static const int min_units = [] { const char* e = getenv("MMGL_GEMM_8P_SPLIT_MIN_UNITS"); return e ? atoi(e) : 24; }();
+        if (units < min_units) return;
         int s = (224 + tiles - 1) / tiles;
         if (s > 8) s = 8;
         if (s > units / 2) s = units / 2;
