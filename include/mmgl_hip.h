@@ -261,6 +261,20 @@ int mmgl_gemm_nt(const void* x, int ldx, const void* W, int ldw, const void* bia
                  void* y, int ldy, int M, int N, int K, int act, float out_scale, void* workspace, size_t workspace_bytes,
                  int dtype, void* stream);
 int mmgl_relu_bwd(const void* dy, const void* y, void* out, size_t n, int dtype, void* stream);
+/* The ReLU mask of a frozen FFN as bits (replaces: keeping relu(fc1(x)) [M, ffn] for autograd's threshold_backward of
+ * model/modelling_cross_attention.py:352-355, and re-reading it in fc2's dgrad).
+ *   mmgl_gemm_nt_relu_bits: y = relu((x W^T + bias) * out_scale) as mmgl_gemm_nt with act = 1, plus bits_out: one bit per
+ *     output element (y > 0), mmgl_gemm_nt_relu_bits_bytes() bytes of caller memory (8 KiB per 256 x 256 output tile).
+ *   mmgl_gemm_nt_masked: y = (x W^T) * out_scale where the bit of that element is set, 0 elsewhere -- fc2's dgrad with fc1's
+ *     ReLU backward folded in, reading 16 bytes of mask per lane and tile instead of the [M, ffn] activation.
+ * The bits are private to the persistent kernel's tile -> lane mapping: write and apply them with the same M and N.
+ * mmgl_gemm_nt_relu_bits_bytes returns 0 for shapes / dtypes that do not run as whole tiles of that kernel (then use
+ * mmgl_gemm_nt with act = 1 and its zmask argument instead). */
+size_t mmgl_gemm_nt_relu_bits_bytes(int M, int N, int K, int ldx, int ldw, int ldy, int dtype);
+int mmgl_gemm_nt_relu_bits(const void* x, int ldx, const void* W, int ldw, const void* bias, void* y, int ldy, void* bits_out,
+                           int M, int N, int K, float out_scale, int dtype, void* stream);
+int mmgl_gemm_nt_masked(const void* x, int ldx, const void* W, int ldw, const void* bits_in, void* y, int ldy, int M, int N, int K,
+                        float out_scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Elementwise pieces of frozen Llama-family decoder layers (BASELINE.json config 5; the reference's fork is OPT-only,

@@ -62,6 +62,9 @@ SIGNATURES = {
     "mmgl_activation_fwd": (I, [P, P, Z, I, I, P]),
     "mmgl_gemm_nt_fast": (I, [I, I, I, I, I, I, I]),
     "mmgl_gemm_nt_workspace": (Z, [I, I, I, I, I, I, I]),
+    "mmgl_gemm_nt_relu_bits_bytes": (Z, [I, I, I, I, I, I, I]),
+    "mmgl_gemm_nt_relu_bits": (I, [P, I, P, I, P, P, I, P, I, I, I, F, I, P]),
+    "mmgl_gemm_nt_masked": (I, [P, I, P, I, P, P, I, I, I, I, F, I, P]),
     "mmgl_gemm_nt": (I, [P, I, P, I, P, P, P, P, I, I, I, I, I, F, P, Z, I, P]),
     "mmgl_relu_bwd": (I, [P, P, P, Z, I, P]),
     "mmgl_rope_inplace": (I, [P, P, Z, I, I, I, I, I, I, I, P]),

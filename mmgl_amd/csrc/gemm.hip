@@ -1312,6 +1312,36 @@ extern "C" int mmgl_gemm_nt(const void* x, int ldx, const void* W, int ldw, cons
     return rc;
 }
 
+// ReLU mask as bits.  fc1 of a frozen FFN writes one bit per element of relu(x W1^T + b1) beside the activation; fc2's dgrad
+// (dh = (dy W2) where h > 0) applies them in its epilogue instead of re-reading the [M, ffn] activation: 16 bytes per lane and
+// tile instead of 256, and the activation need not be kept for the backward pass.  Only for shapes that run as whole 256x256
+// tiles on the persistent kernel (the bits are lane-private: both kernels must map tiles to lanes the same way).
+extern "C" size_t mmgl_gemm_nt_relu_bits_bytes(int M, int N, int K, int ldx, int ldw, int ldy, int dtype) {
+    if (dtype != MMGL_BF16 || !tune_gemm_8p() || !gemm8p_supported(M, N, K, ldx, ldw, ldy)) return 0;
+    if (cdiv(M, 256) * cdiv(N, 256) < tune_gemm_8p_min_tiles()) return 0;
+    static const int on = [] { const char* e = getenv("MMGL_GEMM_RELU_BITS"); return e ? atoi(e) : 1; }();
+    return on ? gemm8p_bits_bytes(M, N) : 0;
+}
+
+extern "C" int mmgl_gemm_nt_relu_bits(const void* x, int ldx, const void* W, int ldw, const void* bias, void* y, int ldy, void* bits_out,
+                                      int M, int N, int K, float out_scale, int dtype, void* stream) {
+    MMGL_CHECK_ARG(x && W && y && bits_out, "mmgl_gemm_nt_relu_bits: null pointer");
+    MMGL_CHECK_ARG(mmgl_gemm_nt_relu_bits_bytes(M, N, K, ldx, ldw, ldy, dtype) > 0,
+                   "mmgl_gemm_nt_relu_bits: shape M=%d N=%d K=%d (ld %d %d %d, dtype %d) does not run as whole tiles of the persistent kernel", M, N, K, ldx, ldw, ldy, dtype);
+    return launch_gemm8p((const bf16*)x, ldx, (const bf16*)W, ldw, (bf16*)y, ldy, (const bf16*)bias, nullptr, nullptr, M, N, K, MMGL_ACT_RELU,
+                         out_scale, (hipStream_t)stream, nullptr, 0, (unsigned*)bits_out, nullptr);
+}
+
+extern "C" int mmgl_gemm_nt_masked(const void* x, int ldx, const void* W, int ldw, const void* bits_in, void* y, int ldy, int M, int N, int K,
+                                   float out_scale, int dtype, void* stream) {
+    MMGL_CHECK_ARG(x && W && y && bits_in, "mmgl_gemm_nt_masked: null pointer");
+    MMGL_CHECK_ARG(ldx + 127 >= K && ldw >= K && ldy >= N, "mmgl_gemm_nt_masked: leading dimensions (%d, %d, %d) smaller than the rows (K=%d, N=%d)", ldx, ldw, ldy, K, N);
+    MMGL_CHECK_ARG(mmgl_gemm_nt_relu_bits_bytes(M, N, K, ldx, ldw, ldy, dtype) > 0,
+                   "mmgl_gemm_nt_masked: shape M=%d N=%d K=%d (ld %d %d %d, dtype %d) does not run as whole tiles of the persistent kernel", M, N, K, ldx, ldw, ldy, dtype);
+    return launch_gemm8p((const bf16*)x, ldx, (const bf16*)W, ldw, (bf16*)y, ldy, nullptr, nullptr, nullptr, M, N, K, MMGL_ACT_NONE, out_scale,
+                         (hipStream_t)stream, nullptr, 0, nullptr, (const unsigned*)bits_in);
+}
+
 /* dy * (y > 0): backward of a stand-alone ReLU (in place allowed) */
 extern "C" int mmgl_relu_bwd(const void* dy, const void* y, void* out, size_t n, int dtype, void* stream) {
     MMGL_CHECK_ARG(dy && y && out, "mmgl_relu_bwd: null pointer");

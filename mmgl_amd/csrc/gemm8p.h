@@ -9,7 +9,10 @@ int gemm8p_splits(int M, int N, int K);      // K splits for few-tile outputs (0
 size_t gemm8p_split_bytes(int M, int N, int K);   // fp32 partial tiles of the K-split path (caller's scratch)
 int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, const bf16* resid,
                   const bf16* zmask, int M, int N, int K, int act, float scale, hipStream_t st, float* part = nullptr,
-                  size_t part_bytes = 0);
+                  size_t part_bytes = 0, unsigned* bits_out = nullptr, const unsigned* bits_in = nullptr);
+// ReLU mask as bits: 8 KiB per 256x256 output tile ([tile][8 waves][64 lanes][4 dwords], lane-private: the kernel that applies
+// them has the same tile -> lane mapping as the one that wrote them); written by the act = 1 epilogue, applied by the plain one
+inline size_t gemm8p_bits_bytes(int M, int N) { return (size_t)cdiv(M, 256) * cdiv(N, 256) * 8192; }
 
 // weight gradient on the same structure (gemm8p_tt.hip): Out[RB][RA] = scale * sum_m B[m][rb] A[m][ra], both operands k-major
 int gemm8p_tt_splits(int RA, int RB, int M);

@@ -54,6 +54,8 @@ struct P8Args {
     int tiles_m, tiles_n, total;
     int nsplit;            // K splits per output tile (1 = none): work item = (tile, split), fp32 partial tiles into `part`
     float* part;           // [nsplit][M][N] fp32 (ACT = 5 kernels)
+    unsigned* bits_out;    // ACT = 1 kernels: one bit per output element (y > 0), [tile][wave][lane][4 dwords], or NULL
+    const unsigned* bits_in;   // ZR kernels: the same bits as the mask of this output (instead of a zmask tensor), or NULL
     int tile0;             // first output tile of this launch (a hybrid launch: full tiles first, the rest as K-split items)
     int stagger;           // start delay per CU group in units of 256 clocks (0 = none)
     int stag_mask;         // CU groups - 1 (power of two; group = CU index within its XCD & mask)
@@ -105,6 +107,9 @@ __device__ __forceinline__ int p8_lane() {
 // 2 % behind on the K = 768 shape.
 #ifndef P8_STORE_AUX
 #define P8_STORE_AUX 18
+#endif
+#ifndef P8_ZMASK_AUX
+#define P8_ZMASK_AUX 2               // ... of the zmask tile loads of the epilogue
 #endif
 #ifndef P8_PART_AUX
 #define P8_PART_AUX 0                // ... of the K-split scratch tiles (read back by the finish kernel right away)
@@ -310,15 +315,28 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         };
         const __amdgpu_buffer_rsrc_t dY = y_desc(a.Y, m0);
         bf16x8 pre[16];
+        p8_u32x4 mbits = {0u, 0u, 0u, 0u};
         if constexpr (ZR) {
             const __amdgpu_buffer_rsrc_t dZ = y_desc(a.zmask ? a.zmask : a.resid, m0);
+            if (a.bits_in) {                         // 16 bytes per lane instead of 16 x 16: the ReLU mask as bits (see bits_out)
+                mbits = *(const p8_u32x4*)(a.bits_in + ((size_t)((a.tile0 + par * G + wg) * 8 + wave) * 64 + ln) * 4);
+            } else if (a.zmask) {                           // read once, never again: non-temporal (-2.5 % on the fc2 dgrad); a residual tile is
+#pragma unroll                                       // the stream the next kernels read too: default policy (nt: +1.5 %)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+                    for (int j = 0; j < 4; ++j) {
+                        const int J0 = (q == 0 || q == 1) ? 0 : 4, T0 = (q == 0 || q == 3) ? 0 : 2;
+                        pre[q * 4 + j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dZ, y_off(J0 + j, T0), 0, P8_ZMASK_AUX));
+                    }
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int J0 = (q == 0 || q == 1) ? 0 : 4, T0 = (q == 0 || q == 3) ? 0 : 2;
-                    pre[q * 4 + j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dZ, y_off(J0 + j, T0), 0, 0));
-                }
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int J0 = (q == 0 || q == 1) ? 0 : 4, T0 = (q == 0 || q == 3) ? 0 : 2;
+                        pre[q * 4 + j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dZ, y_off(J0 + j, T0), 0, 0));
+                    }
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -334,7 +352,9 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { acc[T0][J0 + j] *= a.scale; acc[T0 + 1][J0 + j] *= a.scale; }
             }
-            // MODE (wave-uniform, ZR kernels): 1 = zmask only (applied to the packed bf16 output), 2 = residual only, 3 = both
+            unsigned qbits = 0;                      // ACT = 1: (y > 0) bits of this quadrant, byte j = vector j
+            // MODE (wave-uniform, ZR kernels): 1 = zmask only (applied to the packed bf16 output), 2 = residual only, 3 = both,
+            // 4 = mask bits only
             auto rows = [&](auto mode_tag) __attribute__((always_inline)) {
                 constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
@@ -366,6 +386,17 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
                             asm("v_pk_max_i16 %0, %1, 0" : "=v"(w) : "v"(w));     // ReLU on two bf16: a negative bf16 is a negative int16
                             ob[e] = w;
                         }
+                        if (a.bits_out) {                                        // wave-uniform
+                            unsigned by = 0;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                unsigned t = ob[e];
+                                asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(t) : "v"(t));      // each half: 0 / 1 (after the ReLU: > 0 <=> != 0)
+                                t |= t >> 15;                                                           // bit 0 = low half, bit 1 = high half (bit 16: garbage)
+                                by |= t << (2 * e);
+                            }
+                            qbits |= (by & 0xffu) << (8 * j);
+                        }
                     }
                     if constexpr (MODE == 1) {
                         // zmask > 0 on the raw bf16 pairs: negatives -> 0, positives -> 1, then 0 - that = 0xffff / 0 per half
@@ -377,6 +408,17 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
                             ob[e] &= m;
                         }
                     }
+                    if constexpr (MODE == 4) {
+                        const unsigned by = mbits[q] >> (8 * j);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            unsigned t = (by >> (2 * e)) & 3u;
+                            t = (t | (t << 15)) & 0x00010001u;                   // the two bits, one per half
+                            unsigned mk;
+                            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(mk) : "v"(t), "v"(0xffffu));      // 0 / 0xffff per half (full-rate multiply)
+                            ob[e] &= mk;
+                        }
+                    }
 #if P8_ABLATE & 2
                     asm volatile("" :: "v"(ob));
 #else
@@ -385,9 +427,13 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
                 }
             };
             if constexpr (!ZR) rows(std::integral_constant<int, 0>());
+            else if (a.bits_in) rows(std::integral_constant<int, 4>());
             else if (a.zmask && a.resid) rows(std::integral_constant<int, 3>());
             else if (a.zmask) rows(std::integral_constant<int, 1>());
             else rows(std::integral_constant<int, 2>());
+            if constexpr (ACT == 1 && !ZR) {
+                if (a.bits_out) a.bits_out[((size_t)((a.tile0 + par * G + wg) * 8 + wave) * 64 + ln) * 4 + q] = qbits;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { acc[T0][J0 + j] = vzero<f32x4>(); acc[T0 + 1][J0 + j] = vzero<f32x4>(); }
         }
@@ -683,7 +729,8 @@ size_t gemm8p_split_bytes(int M, int N, int K) {
 }
 
 int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, const bf16* resid,
-                  const bf16* zmask, int M, int N, int K, int act, float scale, hipStream_t st, float* part, size_t part_bytes) {
+                  const bf16* zmask, int M, int N, int K, int act, float scale, hipStream_t st, float* part, size_t part_bytes,
+                  unsigned* bits_out, const unsigned* bits_in) {
     if (!gemm8p_supported(M, N, K, ldx, ldw, ldy))
         MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm8p: shape M=%d N=%d K=%d (ld %d %d %d) not supported", M, N, K, ldx, ldw, ldy);
     P8Args a;
@@ -692,6 +739,11 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
     a.tiles_m = cdiv(M, 256); a.tiles_n = cdiv(N, 256); a.total = a.tiles_m * a.tiles_n;
     a.nsplit = 1;
     a.part = nullptr;
+    a.bits_out = bits_out;
+    a.bits_in = bits_in;
+    if (bits_out && (act != 1 || resid || zmask)) MMGL_FAIL(MMGL_ERR_INVALID, "gemm8p: mask bits are written by the plain ReLU epilogue only");
+    if (bits_in && (zmask || resid || act != 0)) MMGL_FAIL(MMGL_ERR_INVALID, "gemm8p: mask bits are applied by the plain epilogue only");
+    if (bits_out || bits_in) part = nullptr;             // whole tiles only: the bits are indexed by (tile, wave, lane)
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -732,7 +784,7 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
         if (const char* e = getenv("MMGL_P8_TRACE")) a.trace = (long long*)strtoull(e, nullptr, 0);
         if (const char* e = getenv("MMGL_P8_TRACE_WG")) a.trace_wg = atoi(e);
 #endif
-        const bool zr = resid || zmask;
+        const bool zr = resid || zmask || bits_in;
 #define P8_LAUNCH(A, Z) hipLaunchKernelGGL((gemm8p_kernel<A, Z>), dim3(grid), dim3(512), P8_LDS_TOTAL, st, a)
         switch (act) {
             case 0: if (zr) P8_LAUNCH(0, true); else P8_LAUNCH(0, false); break;

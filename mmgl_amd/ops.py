@@ -752,6 +752,37 @@ def gemm_nt(x2, w, bias=None, residual=None, zmask=None, act=0, out_scale=1.0, K
     return y
 
 
+def relu_bits_bytes(M, N, K, ldx, ldw, ldy, dtype):
+    """Bytes of the ReLU mask bits of an [M, N] = relu(x W^T) output (0: that shape does not run as whole tiles of the persistent
+    kernel, or the dtype is not bf16 -> keep the activation as the mask)."""
+    if dtype != torch.bfloat16:
+        return 0
+    return lib().mmgl_gemm_nt_relu_bits_bytes(M, N, K, ldx, ldw, ldy, _lib.BF16)
+
+
+def gemm_nt_relu_bits(x2, w, bias, out, K=None):
+    """out = relu(x2[:, :K] @ w^T + bias) plus one bit per element (out > 0), lane-private to the persistent GEMM's tiling:
+    (out, bits uint8 [nbytes]).  Callers check relu_bits_bytes() > 0 first.  No autograd."""
+    M, N = x2.shape[0], w.shape[0]
+    K = x2.shape[1] if K is None else K
+    nb = relu_bits_bytes(M, N, K, x2.stride(0), w.stride(0), out.stride(0), x2.dtype)
+    if not nb:
+        raise ValueError("gemm_nt_relu_bits: shape not eligible (relu_bits_bytes == 0)")
+    bits = torch.empty(nb, dtype=torch.uint8, device=x2.device)
+    _lib.call("mmgl_gemm_nt_relu_bits", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x2.element_size(), tag=f"{M}x{N}x{K}+b+a1+bits"),
+              ptr(x2), x2.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), ptr(bits), M, N, K, 1.0, dtype_code(x2), stream_ptr())
+    return out, bits
+
+
+def gemm_nt_masked(x2, w, bits, out, K=None):
+    """out = (x2[:, :K] @ w^T) where the element's bit is set, 0 elsewhere (bits from gemm_nt_relu_bits of the same [M, N]).  No autograd."""
+    M, N = x2.shape[0], w.shape[0]
+    K = x2.shape[1] if K is None else K
+    _lib.call("mmgl_gemm_nt_masked", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x2.element_size(), tag=f"{M}x{N}x{K}+bits"),
+              ptr(x2), x2.stride(0), ptr(w), w.stride(0), ptr(bits), ptr(out), out.stride(0), M, N, K, 1.0, dtype_code(x2), stream_ptr())
+    return out
+
+
 def _gemm_nt_padded(x2, w, bias=None, zmask=None, act=0, K=None):
     """gemm_nt for feature counts the MFMA kernels cannot address (K not a multiple of one 16-byte chunk, N not a multiple
     of 8 -- tiny test vocabularies, the Laplacian-PE width): operands are zero-padded, the result sliced back."""
@@ -769,7 +800,7 @@ def _gemm_nt_padded(x2, w, bias=None, zmask=None, act=0, K=None):
     return y[:, :N].contiguous() if pn else y
 
 
-def frozen_dgrad(g, weight, zmask=None, out=None):
+def frozen_dgrad(g, weight, zmask=None, out=None, bits=None):
     """dx[M,K] = g[M,N] @ W[N,K] for a frozen W  ==  an NT GEMM against the cached W^T [K, Npad].  The contraction length is
     padded to a multiple of 128 with zero columns of W^T (lm_head: N = vocab = 50272) and g is read with its own row stride.
     No autograd."""
@@ -782,6 +813,8 @@ def frozen_dgrad(g, weight, zmask=None, out=None):
     if out is None and zmask is not None and zmask.stride(0) != zmask.shape[1]:
         # the mask (a ReLU output kept with a padded row pitch, see _ffn_pitch) shares the output's row stride in the epilogue
         out = torch.empty(zmask.shape[0], zmask.stride(0), dtype=g.dtype, device=g.device)[:, :zmask.shape[1]]
+    if bits is not None:                                      # the ReLU mask as bits (see _FrozenLinear): `out` carries the row pitch
+        return gemm_nt_masked(g, wt, bits, out, K=kk)
     if out is not None and kk % (8 if g.dtype == torch.bfloat16 else 4) == 0 and K % 8 == 0:
         return gemm_nt(g, wt, zmask=zmask, K=kk, out=out)
     dx = _gemm_nt_padded(g, wt, zmask=zmask, K=kk)
@@ -819,7 +852,7 @@ def _row_strided(t2, cols, n_out):
 
 class _FrozenLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act, mask_dx, premasked, residual=None):
+    def forward(ctx, x, weight, bias, act, mask_dx, premasked, residual=None, relu_bits=None, relu_pitch=0):
         require_cuda(x, weight)
         K, N = weight.shape[1], weight.shape[0]
         x2 = _row_strided(x.reshape(-1, K), K, N)
@@ -832,7 +865,14 @@ class _FrozenLinear(torch.autograd.Function):
             pitch = _ffn_pitch(x2.shape[0], N, K, x.dtype) if (premasked and residual is None) else N
             if pitch != N:                   # fc1 of a frozen FFN: the consumer (fc2, mask_dx) reads it with its row stride
                 out = torch.empty(*x.shape[:-1], pitch, dtype=x.dtype, device=x.device)[..., :N]
-                y = gemm_nt(x2, w.contiguous(), b, act=act, out=out.reshape(-1, N))
+                wc = w.contiguous()
+                if act == 1 and relu_bits_bytes(x2.shape[0], N, K, x2.stride(0), K, pitch, x.dtype):
+                    # the ReLU mask leaves as bits beside the activation: fc2's backward applies those (16 bytes per lane and
+                    # tile) instead of re-reading -- and keeping -- the [M, ffn] activation
+                    y, bits = gemm_nt_relu_bits(x2, wc, b, out.reshape(-1, N))
+                    _FrozenLinear._last_bits = (bits, pitch)
+                else:
+                    y = gemm_nt(x2, wc, b, act=act, out=out.reshape(-1, N))
             else:
                 out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
                 r2 = None if residual is None else residual.reshape(-1, N).contiguous()
@@ -844,8 +884,15 @@ class _FrozenLinear(torch.autograd.Function):
                 y = y + residual.reshape(-1, N)
         ctx.has_resid = residual is not None
         # premasked: the consumer folds this layer's ReLU backward into its own dgrad (mask_dx there): differentiate as a plain
-        # linear and keep nothing.  mask_dx: x2 is a ReLU output whose backward rides in this layer's dgrad epilogue.
-        ctx.save_for_backward(weight, y if (act == 1 and not premasked) else None, x2 if mask_dx else None)
+        # linear and keep nothing.  mask_dx: x2 is a ReLU output whose backward rides in this layer's dgrad epilogue -- as the
+        # producer's mask bits when it left some and the dgrad's shape takes them (then x2 itself is not kept), else as x2.
+        ctx.mask_bits = None
+        xkeep = x2 if mask_dx else None
+        if mask_dx and relu_bits is not None:
+            if x2.dtype == torch.bfloat16 and x2.stride(0) == relu_pitch and N % 128 == 0 and \
+                    relu_bits_bytes(x2.shape[0], K, N, N, N, relu_pitch, x2.dtype) == relu_bits.numel():
+                ctx.mask_bits, xkeep = (relu_bits, relu_pitch), None
+        ctx.save_for_backward(weight, y if (act == 1 and not premasked) else None, xkeep)
         ctx.act = 0 if premasked else act
         ctx.xshape = x.shape
         return out if out is not None else y.view(*x.shape[:-1], N)
@@ -862,8 +909,13 @@ class _FrozenLinear(torch.autograd.Function):
             g = gm
         elif ctx.act:
             raise RuntimeError("frozen_linear: only the ReLU epilogue is differentiable")
-        dx = frozen_dgrad(g, weight, zmask=xmask)
-        return dx.reshape(ctx.xshape), None, None, None, None, None, (dy if ctx.has_resid else None)
+        if ctx.mask_bits is not None:
+            bits, pitch = ctx.mask_bits
+            buf = torch.empty(g.shape[0], pitch, dtype=g.dtype, device=g.device)[:, :K]
+            dx = frozen_dgrad(g, weight, out=buf, bits=bits)
+        else:
+            dx = frozen_dgrad(g, weight, zmask=xmask)
+        return dx.reshape(ctx.xshape), None, None, None, None, None, (dy if ctx.has_resid else None), None, None
 
 
 def frozen_linear(x, weight, bias, relu=False, mask_dx=False, bwd_premasked=False, act=None, residual=None):
@@ -884,7 +936,12 @@ def frozen_linear(x, weight, bias, relu=False, mask_dx=False, bwd_premasked=Fals
         raise ValueError("frozen_linear: bwd_premasked needs the ReLU epilogue")
     if residual is not None and (code or residual.shape[:-1] != x.shape[:-1] or residual.shape[-1] != weight.shape[0]):
         raise ValueError("frozen_linear: `residual` ([..., out_features], added in the GEMM epilogue) goes with no activation")
-    return _FrozenLinear.apply(x, weight, bias, code, bool(mask_dx), bool(bwd_premasked), residual)
+    _FrozenLinear._last_bits = None
+    mb = getattr(x, "_mmgl_relu_bits", None) if mask_dx else None
+    y = _FrozenLinear.apply(x, weight, bias, code, bool(mask_dx), bool(bwd_premasked), residual, None if mb is None else mb[0], 0 if mb is None else mb[1])
+    if _FrozenLinear._last_bits is not None:                 # fc1 of a frozen FFN left its ReLU mask as bits: hand them to the consumer
+        y._mmgl_relu_bits, _FrozenLinear._last_bits = _FrozenLinear._last_bits, None
+    return y
 
 
 def frozen_linear_relu(x, weight, bias):

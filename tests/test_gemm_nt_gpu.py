@@ -102,7 +102,11 @@ def test_frozen_ffn_pair_mask_dx(M, d, ffn):
     b2 = (torch.randn(d, device="cuda", generator=g) * 0.1).bfloat16()
     w = torch.randn(M, d, device="cuda", generator=g).bfloat16()
     h = ops.frozen_linear(x, W1, b1, relu=True, bwd_premasked=True)
+    if M >= 2560:                    # whole tiles of the persistent kernel: the ReLU mask travels as bits, h is not kept for backward
+        assert getattr(h, "_mmgl_relu_bits", None) is not None
     y = ops.frozen_linear(h, W2, b2, mask_dx=True)
+    if M >= 2560:
+        assert y.grad_fn.mask_bits is not None and y.grad_fn.saved_tensors[2] is None
     (y.float() * w.float()).sum().backward()
     xr = x.detach().float().requires_grad_()
     hr = torch.relu(F.linear(xr, W1.float(), b1.float()))
@@ -112,6 +116,30 @@ def test_frozen_ffn_pair_mask_dx(M, d, ffn):
     (yr * w.float()).sum().backward()
     assert (y.float() - yr).abs().max().item() <= 3e-2 * yr.abs().max().item() + 1e-2
     assert (x.grad.float() - xr.grad).abs().max().item() <= 3e-2 * xr.grad.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("M,N,K,pitch", [(40960, 8192, 2048, 8320), (5000, 8192, 2048, 8192), (2570, 8208, 2048, 8208)])
+def test_relu_mask_bits_round_trip(M, N, K, pitch):
+    """mmgl_gemm_nt_relu_bits writes (y > 0) as lane-private bits, mmgl_gemm_nt_masked applies them to another product of the same
+    [M, N]: equal to masking with the stored activation itself (ragged last tiles, padded row pitch)."""
+    from mmgl_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    W1 = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).bfloat16()
+    b1 = (torch.randn(N, device="cuda", generator=g) * 0.1).bfloat16()
+    dy = torch.randn(M, 2048, device="cuda", generator=g).bfloat16()
+    W2t = (torch.randn(N, 2048, device="cuda", generator=g) * 2048 ** -0.5).bfloat16()      # = W2^T: [ffn, d_out]
+    assert ops.relu_bits_bytes(M, N, K, K, K, pitch, torch.bfloat16) == ((M + 255) // 256) * ((N + 255) // 256) * 8192
+    h = torch.empty(M, pitch, device="cuda", dtype=torch.bfloat16)[:, :N]
+    _, bits = ops.gemm_nt_relu_bits(x, W1, b1, h)
+    want_h = ops.gemm_nt(x, W1, b1, act=1)
+    assert torch.equal(h, want_h)
+    dh = torch.full((M, pitch), float("nan"), device="cuda", dtype=torch.bfloat16)[:, :N]
+    ops.gemm_nt_masked(dy, W2t, bits, dh)
+    want = ops.gemm_nt(dy, W2t, zmask=want_h.contiguous())
+    assert torch.equal(dh, want)
+    assert ops.relu_bits_bytes(1000, 512, 256, 256, 256, 512, torch.bfloat16) == 0            # too few tiles: no bits
+    assert ops.relu_bits_bytes(M, N, K, K, K, pitch, torch.float32) == 0
 
 
 def test_frozen_lm_head_padded_dgrad():
