@@ -520,6 +520,61 @@ class _LoraLinear(torch.autograd.Function):
         return dx.view(shape), None, None, dA.to(adt), dB.to(bdt), None
 
 
+def _wgrad_only(dy2, x2, w_like, scale):
+    """dW [N, K] = scale * dy2^T x2 through mmgl_linear_bwd (no dx, no bias gradient); w_like: any [N, K] tensor of the dtype."""
+    M, K = x2.shape
+    N = dy2.shape[1]
+    code = dtype_code(x2)
+    dw = torch.empty(N, K, dtype=x2.dtype, device=x2.device)
+    ws = _ws(lib().mmgl_linear_bwd_workspace(M, N, K, 0, code), x2.device)
+    _lib.call("mmgl_linear_bwd", dict(flops=2.0 * M * N * K, bytes=float(M * K + N * K + M * N) * x2.element_size()),
+              ptr(dy2), None, ptr(x2), ptr(w_like), None, ptr(dw), None, ptr(ws), ws.numel(), M, N, K, 0, float(scale), 0, 0, code, stream_ptr())
+    return dw
+
+
+_LORA_ONE_NODE = os.environ.get("MMGL_LORA_ONE_NODE", "1") != "0"      # A/B switch
+
+
+class _LoraLinearBig(torch.autograd.Function):
+    """lora_linear for large bf16 shapes as ONE autograd node: the same seven GEMMs the composed form ran (rank zero-padded to
+    256), but dx = dy W + (dy B) A leaves the second GEMM's residual epilogue instead of an ATen add, the pads / slices of the
+    adapter gradients happen once, and nothing but x, x A^T and the padded factors is kept (config 4: 201 adds and 123 copies
+    per step came from autograd's bookkeeping around the composed form)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, lora_A, lora_B, scale):
+        require_cuda(x, weight)
+        K, N, r = x.shape[-1], weight.shape[0], lora_A.shape[0]
+        rp = (-r) % 256
+        A_pad = F.pad(lora_A.detach().to(x.dtype), (0, 0, 0, rp)).contiguous()          # [256, K]
+        B_pad = F.pad(lora_B.detach().to(x.dtype), (0, rp)).contiguous()                # [N, 256]
+        x2 = x.reshape(-1, K).contiguous()
+        xa = gemm_nt(x2, A_pad)                                                         # [M, 256]
+        delta = gemm_nt(xa, B_pad, out_scale=scale)                                     # [M, N]
+        w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+        b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
+        out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+        gemm_nt(x2, w.contiguous(), b, residual=delta, out=out.view(-1, N))
+        ctx.save_for_backward(x2, xa, weight, A_pad, B_pad)
+        ctx.meta = (x.shape, float(scale), r, lora_A.dtype, lora_B.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xa, weight, A_pad, B_pad = ctx.saved_tensors
+        xshape, scale, r, adt, bdt = ctx.meta
+        N = weight.shape[0]
+        g = dy.reshape(-1, N).contiguous()
+        dxa = gemm_nt(g, B_pad.t().contiguous(), out_scale=scale)                       # (dy B) * scale  [M, 256]
+        dB = _wgrad_only(g, xa, B_pad, scale) if ctx.needs_input_grad[4] else None      # [N, 256]
+        dA = _wgrad_only(dxa, x2, A_pad, 1.0) if ctx.needs_input_grad[3] else None      # [256, K]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx0 = frozen_dgrad(g, weight)                                               # dy W
+            dx = gemm_nt(dxa, A_pad.t().contiguous(), residual=dx0).view(xshape)        # + (dy B) A in the epilogue
+        return (dx, None, None, None if dA is None else dA[:r].to(adt), None if dB is None else dB[:, :r].contiguous().to(bdt), None)
+
+
 def lora_linear(x, weight, bias, lora_A, lora_B, scale):
     """x W^T + b + scale * (x A^T) B^T with a frozen base weight (peft LoRA semantics, lora_dropout = 0).
     Large bf16 shapes: the base product runs on the persistent ping-pong GEMM with the low-rank update
@@ -533,6 +588,8 @@ def lora_linear(x, weight, bias, lora_A, lora_B, scale):
         # the rank is zero-padded to 256 (autograd slices the gradients back): every product of the low-rank path -- x A^T,
         # (x A^T) B^T, and in backward dy B, (dy B) A, (dy B)^T x, dy^T (x A^T) -- is then a 256-wide GEMM the large-tile kernels
         # (and their K splits) carry, instead of a 16-wide one on a handful of workgroups
+        if _LORA_ONE_NODE and x.dtype == torch.bfloat16 and K % 8 == 0 and N % 8 == 0:
+            return _LoraLinearBig.apply(x, weight, bias, lora_A, lora_B, float(scale))
         rp = (-lora_A.shape[0]) % 256
         A_pad = F.pad(lora_A, (0, 0, 0, rp)) if rp else lora_A
         B_pad = F.pad(lora_B, (0, rp)) if rp else lora_B
