@@ -9,6 +9,8 @@
 // Same schedule as gemm8p_kernel: 8 waves, wave (wr, wc) owns 128 (rb) x 64 (ra) of a 256 x 256 tile, the two waves of a SIMD
 // half a phase apart, one unit per phase (Ba: rb columns 0-63 of each wave's block, Ab-of-this-K-tile: ra columns 32-63,
 // Bb: rb 64-127, Aa-of-the-next-K-tile: ra 0-31), issued 6 phases ahead, counted vmcnt, stream continuous across work items.
+// Differences in the phase body: the fragment reads are inline-asm transpose reads (hipcc puts vmcnt(0) ahead of the builtin
+// form while LDS-DMA writes are in flight) and the fragments of phase p+1 are read inside the MFMA cluster of phase p (T8_ROLL).
 // Work item = (output tile, K split): a 2048 x 2048 weight is only 64 tiles, so the M rows are cut into `nsplit` ranges whose
 // fp32 partial tiles a fixed-order reduce folds afterwards (deterministic, no atomics).
 // Needs (M / nsplit) % 128 == 0 and >= 256; RA % 256 == 0 and RB % 256 == 0 under a K split (unsplit: multiples of 8, ragged last
