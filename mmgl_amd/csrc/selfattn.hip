@@ -11,6 +11,7 @@
 #define MMGL_XATTN_QT_FORCE SA_QT_FORCE
 #endif
 #include "attn_common.h"
+#include "selfattn32.h"
 #include <type_traits>
 
 namespace {
@@ -1110,6 +1111,12 @@ int sa_check(const char* who, int B, int H, int T, int D, int dtype) {
 
 }  // namespace
 
+// MMGL_SELFATTN_32=0: the 16x16 kernels of this file for bf16 head_dim 64 / 128 too (same-box A/B of selfattn32.hip)
+static bool use_sa32() {
+    static const int on = [] { const char* e = getenv("MMGL_SELFATTN_32"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
 static int sa_ld(const char* who, int& ld, int H, int D) {
     if (ld == 0) ld = H * D;
     MMGL_CHECK_ARG(ld >= H * D && ld % 8 == 0, "%s: row stride %d must be 0 (packed) or a multiple of 8 >= H*D = %d", who, ld, H * D);
@@ -1123,6 +1130,7 @@ extern "C" int mmgl_selfattn_prefix_fwd(const void* q, const void* k, const void
     MMGL_CHECK_ARG(q && k && v && key_valid && out && lse && P >= 0, "mmgl_selfattn_prefix_fwd: bad arguments");
     if ((rc = sa_ld("mmgl_selfattn_prefix_fwd", ld_q, H, D)) || (rc = sa_ld("mmgl_selfattn_prefix_fwd", ld_kv, H, D))) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMGL_BF16 && use_sa32() && sa32_supported(D, T + P)) return sa32_fwd(q, k, v, key_valid, out, lse, B, H, T, P, D, ld_q, ld_kv, st);
     if (dtype == MMGL_BF16) { SA_DISPATCH(sa_fwd, bf16, q, k, v, key_valid, out, lse, B, H, T, ld_q, P, ld_kv, st) }
     SA_DISPATCH(sa_fwd, float, q, k, v, key_valid, out, lse, B, H, T, ld_q, P, ld_kv, st)
 }
@@ -1168,6 +1176,7 @@ extern "C" int mmgl_encattn_fwd(const void* q, const void* k, const void* v, con
     MMGL_CHECK_ARG(ld_in >= H * D && ld_out >= H * D && ld_in % 8 == 0 && ld_out % 8 == 0,
                    "mmgl_encattn_fwd: row strides (%d, %d) must be >= H*D = %d and multiples of 8 elements", ld_in, ld_out, H * D);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMGL_BF16 && use_sa32() && sa32_supported(D, max_len)) return sa32_enc_fwd(q, k, v, cu_seqlens, out, nseq, H, D, ld_in, ld_out, max_len, q_rows, st);
     if (dtype == MMGL_BF16) { SA_DISPATCH(enc_fwd, bf16, q, k, v, cu_seqlens, out, nseq, H, ld_in, ld_out, max_len, q_rows, st) }
     SA_DISPATCH(enc_fwd, float, q, k, v, cu_seqlens, out, nseq, H, ld_in, ld_out, max_len, q_rows, st)
 }

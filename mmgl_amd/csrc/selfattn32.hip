@@ -1,0 +1,415 @@
+// Flash attention for gfx950 on v_mfma_f32_32x32x16_bf16: the bf16, head_dim 64 / 128 kernels behind mmgl_selfattn_fwd /
+// mmgl_selfattn_prefix_fwd (causal self-attention of the frozen decoder layers, reference model/modelling_cross_attention.py:
+// 203-271 with the masks of :51-79, 455-476) and mmgl_encattn_fwd (packed bidirectional attention of the frozen neighbor
+// encoders, :978-1027).  selfattn.hip keeps the fp32 / small-head_dim kernels and the C ABI entry points.
+//
+// Why this kernel exists.  At the OPT-1.3B shape (B = 64, H = 32, T = 640, D = 64) Q, K, V and O are 671 MB per call: 112 us at
+// 6 TB/s, against 43 us of MFMA time -- the forward pass is HBM-bound once its inner loop stops being VALU-bound.  The 16x16 kernel
+// it replaces issued ~560 instructions per 64-key tile and wave (32 MFMAs among them) and ran at 300 us.  Here:
+//   * workgroup = 4 waves = 128 query rows of one (batch, head); wave = 32 rows; 2-3 workgroups per CU (12 / 8 waves), so a SIMD
+//     always has one wave in its MFMAs while another does softmax arithmetic, without a hand-built ping-pong.
+//   * swapped products on 32x32x16 MFMAs: S^T = K Q^T (A = K rows from LDS, B = Q^T from registers), O^T += V^T P^T.  A lane owns
+//     ONE query row (two lanes per row: hi = lane >> 5 splits the keys 4-by-4), so row max / sum are in-lane chains plus one
+//     v_permlane32_swap, and the S^T accumulator layout IS the B-operand layout of the second product: P never leaves its lane.
+//   * K / V tiles (64 keys) travel global -> LDS by LDS-DMA (buffer_load ... lds, 1 KiB pieces, whole rows per 8 / 16 lanes: fully
+//     coalesced) into a ring of NS slots, one s_barrier per tile, counted vmcnt (the next tile stays in flight across the barrier).
+//     No register staging, no ds_write.  The 16-byte slot of a row is XOR-swizzled on the SOURCE side (the DMA destination is
+//     lane-linear): K rows so that the ds_read_b128 A-fragment reads are bank-conflict free, V rows so that the four key rows a
+//     ds_read_b64_tr_b16 touches per 32 lanes fall into four different 64-byte bank quarters.
+//   * masks cost nothing on ordinary tiles: a 64-bit key-valid word per tile (built once per workgroup in LDS) classifies a tile as
+//     all-valid (no masking code runs), all-masked (the tile is SKIPPED: exp(-inf) = 0 exactly, so the result is unchanged -- the
+//     padded middle of a WikiWeb2M sequence, wikiweb2m/data.py:321-333, is 30 % of the keys) or mixed (per-element select, rare);
+//     the causal select runs only on the 32-key blocks the diagonal touches.
+//   * online softmax in the log2 domain with a deferred rescale: O and l are rescaled only when some row's maximum grew by more
+//     than 2^8 since the last rescale (P <= 256 then: bf16 keeps its 8 relative bits, l and O accumulate in fp32), a wave-uniform
+//     branch that is almost never taken after the first tiles.
+#include "attn_common.h"
+#include "selfattn32.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+#define SA32_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define SA32_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifndef SA32_THR
+#define SA32_THR 8.0f             // deferred rescale threshold (log2 units)
+#endif
+#ifndef SA32_ABLATE
+#define SA32_ABLATE 0             // timing experiments only, results are wrong (1: K / V tiles fetched once, 2: no per-tile barrier, 4: no exp / max / sum)
+#endif
+#ifndef SA32_NS64
+#define SA32_NS64 2               // ring slots at head_dim 64 (3: two tiles in flight, 3 workgroups per CU; 2: one tile, 4 workgroups)
+#endif
+#ifndef SA32_VEARLY
+#define SA32_VEARLY 1             // V^T fragments requested before the softmax arithmetic (their latency hides under it)
+#endif
+
+template <int D> struct G32 {
+    static constexpr int KT = 64;                     // keys per tile
+    static constexpr int ROWB = D * 2;                // bytes per K / V row in LDS
+    static constexpr int TILEB = KT * ROWB;           // one operand tile
+    static constexpr int PIECES = TILEB / 1024;       // 1 KiB LDS-DMA pieces per operand tile
+    static constexpr int RPP = 1024 / ROWB;           // rows per piece
+    static constexpr int LPR = 64 / RPP;              // lanes per row of a piece (= 16-byte slots per row)
+    static constexpr int NKS = D / 16;                // contraction steps of S^T = K Q^T
+    static constexpr int NDB = D / 32;                // 32-channel blocks of O^T
+    static constexpr int NS = (D == 64) ? SA32_NS64 : 2;      // ring slots (K tile + V tile each)
+    static constexpr int SLOTB = 2 * TILEB;
+    static constexpr int NP = 2 * PIECES / 4;         // LDS-DMA instructions per wave and tile
+    static constexpr int MAXT = 64;                   // key tiles per sequence the valid-word table holds (4096 keys)
+    static constexpr int LDS = NS * SLOTB + MAXT * 8;
+    static constexpr int OCC = (D == 64) ? (SA32_NS64 == 3 ? 3 : 4) : 2;     // workgroups per CU the kernel is sized for
+};
+template <int D> __device__ __forceinline__ int swz_k(int row) { return D == 64 ? ((row >> 1) & 7) : (row & 15); }
+template <int D> __device__ __forceinline__ int swz_v(int row) { return D == 64 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }
+
+struct SA32Args {
+    const bf16 *q, *k, *v;
+    const uint8_t* valid;      // [B, P + T] (batch mode) or null
+    bf16* out;
+    float* lse;                // [B, H, T] or null
+    const int* cu;             // packed mode: sequence i owns rows cu[i] .. cu[i+1]-1; null = batch mode
+    int B, H, T, P, nqb, ldq, ldk, ldo, q_rows;
+};
+
+__device__ __forceinline__ f32x16 mma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// key (within its 32-key block) of accumulator register r on a lane of half `hi`: (r & 3) + 8 (r >> 2) + 4 hi
+__device__ __forceinline__ constexpr int kreg(int r) { return (r & 3) + 8 * (r >> 2); }
+
+__device__ __forceinline__ void swap32_u32(uint32_t& a, uint32_t& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) {
+    typedef G32<D> G;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int key = lane & 31, hi = lane >> 5;
+
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = vid / a.nqb;
+    const int qblk = CAUSAL ? a.nqb - 1 - vid % a.nqb : vid % a.nqb;      // causal: longest (most key tiles) first
+    const int b = bh / a.H, h = bh % a.H;
+    int Tq, Tk;
+    const bf16 *qb, *kb, *vb;
+    bf16* ob;
+    const uint8_t* valid_row = nullptr;
+    if (a.cu) {
+        const int start = a.cu[b], len = a.cu[b + 1] - start;
+        Tq = min(len, a.q_rows);
+        Tk = len;
+        qb = a.q + (size_t)start * a.ldq + h * D;
+        kb = a.k + (size_t)start * a.ldk + h * D;
+        vb = a.v + (size_t)start * a.ldk + h * D;
+        ob = a.out + (size_t)start * a.ldo + h * D;
+    } else {
+        Tq = a.T;
+        Tk = a.T + a.P;
+        qb = a.q + (size_t)b * a.T * a.ldq + h * D;
+        kb = a.k + (size_t)b * Tk * a.ldk + h * D;
+        vb = a.v + (size_t)b * Tk * a.ldk + h * D;
+        ob = a.out + (size_t)b * a.T * a.ldo + h * D;
+        if (a.valid) valid_row = a.valid + (size_t)b * Tk;
+    }
+    if (qblk * 128 >= Tq) return;                                       // workgroup-uniform, before any barrier
+    const int t0 = qblk * 128 + wave * 32;
+    const int nkt = CAUSAL ? (min(Tq, (qblk + 1) * 128) + a.P + G::KT - 1) / G::KT : (Tk + G::KT - 1) / G::KT;
+
+    const uint32_t ldqB = (uint32_t)a.ldq * 2u, ldkB = (uint32_t)a.ldk * 2u, ldoB = (uint32_t)a.ldo * 2u;
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(qb, (uint32_t)(Tq - 1) * ldqB + D * 2);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (uint32_t)(Tk - 1) * ldkB + D * 2);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (uint32_t)(Tk - 1) * ldkB + D * 2);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(ob, (uint32_t)(Tq - 1) * ldoB + D * 2);
+
+    // ---- per-tile key-valid words (bit s of word j: key 64 j + s exists and is attendable).  The bytes of this wave's first four
+    // tiles are only REQUESTED here (oldest loads of the prologue); they are turned into words after Q and the first K / V tiles
+    // have been requested too, so that the three round trips overlap
+    uint64_t* vbits = (uint64_t*)(smem + G::NS * G::SLOTB);
+    const bool nomask = valid_row == nullptr;                           // branch-free: without a mask the descriptor is empty and reads as 0
+    const __amdgpu_buffer_rsrc_t rvalid = make_rsrc(valid_row, nomask ? 0u : (uint32_t)Tk);
+    uint8_t vraw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vraw[i] = __builtin_amdgcn_raw_buffer_load_b8(rvalid, (uint32_t)((wave + 4 * i) * G::KT + lane), 0, 0);
+
+    // ---- Q^T fragments (B operand of S^T = K Q^T): lane (row = lane & 31, hi) holds channels 16 ks + 8 hi .. + 7
+    const int trow = t0 + key;
+    bf16x8 qf[G::NKS];
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks) qf[ks] = buf_load8<bf16>(rq, (uint32_t)trow * ldqB + (uint32_t)(16 * ks + 8 * hi) * 2u);
+
+    // ---- LDS-DMA of K / V tile j into ring slot `slot`: wave w moves pieces w, w + 4, .. (RPP rows each) of both operands
+    uint32_t kvoff, vvoff;
+    {
+        const int row = G::RPP * wave + lane / G::LPR, sl = lane % G::LPR;
+        kvoff = (uint32_t)row * ldkB + (uint32_t)((sl ^ swz_k<D>(row)) << 4);
+        vvoff = (uint32_t)row * ldkB + (uint32_t)((sl ^ swz_v<D>(row)) << 4);
+    }
+    auto issue = [&](int j, int slot) __attribute__((always_inline)) {
+        char* base = smem + slot * G::SLOTB + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < G::PIECES / 4; ++i) {
+            const int soff = (int)((uint32_t)(j * G::KT + i * 4 * G::RPP) * ldkB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)(base + i * 4096), 16, kvoff, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(base + G::TILEB + i * 4096), 16, vvoff, soff, 0, 0);
+        }
+    };
+    constexpr int PD = G::NS - 1;                                       // tiles in flight
+#pragma unroll
+    for (int j = 0; j < PD; ++j) issue(j, j);                           // unconditional (a tile past the last key reads as zeros): hipcc's vmcnt for Q stays exact
+
+    // ---- fragment addresses (byte offsets inside a slot)
+    // K row `key`, logical 16-byte slot 2 ks + hi, physical slot ^ swz_k(key): one lane base, the step as an XOR at the point of use
+    const int lds0 = (int)(unsigned)(size_t)(lds_void*)smem;
+    const int kbase = key * G::ROWB + (((hi ^ swz_k<D>(key)) & 1) << 4) + ((swz_k<D>(key) & ~1) << 4);
+    // V^T via ds_read_b64_tr_b16: in its 16-lane group lane i points at key row (i >> 2), channels 4 (i & 3) .. + 3 of the group's
+    // 16-channel block and receives channel i of the four rows.  Group gg = lane >> 4: channel block (gg & 1), key half hi = gg >> 1.
+    int vbase;
+    {
+        const int i = lane & 15, gg = lane >> 4;
+        const int row = 4 * (gg >> 1) + (i >> 2);
+        vbase = lds0 + G::TILEB + row * G::ROWB + (((2 * (gg & 1) + ((i & 3) >> 1)) ^ swz_v<D>(row)) << 4) + 8 * (i & 1);
+    }
+
+    f32x16 o[G::NDB];
+#pragma unroll
+    for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m2 = -INFINITY, lsum = 0.f;                                  // running row maximum (log2 units), this lane's share of the row sum
+
+    // this wave's causal bounds: tiles above its diagonal are not computed (it still takes part in barriers and DMA)
+    const bool wave_active = t0 < Tq;
+    const int tl = t0 + 31 + a.P;                                       // last key any row of this wave may see
+    const int jlast = !wave_active ? -1 : (CAUSAL ? min(nkt - 1, tl >> 6) : nkt - 1);
+
+    auto body = [&](auto nb_tag, int j, uint32_t vlo, uint32_t vhi, bool mixed, int slot) __attribute__((always_inline)) {
+        constexpr int NB = decltype(nb_tag)::value;
+        const char* Ks = smem + slot * G::SLOTB;
+        f32x16 s[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < G::NKS; ++ks)
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const bf16x8 kf = *(const bf16x8*)(Ks + blk * 32 * G::ROWB + (kbase ^ (ks << 5)));
+                s[blk] = mma32(kf, qf[ks], s[blk]);
+            }
+        // V^T fragments of ONE 32-channel block db: [blk][jj] = keys 32 blk + 16 jj + {4 hi + 0..3, 8 + 4 hi + 0..3}.  Two register sets:
+        // block db + 1 is requested before block db's MFMAs (its LDS latency hides under them), block 0 before the softmax arithmetic.
+        // The transpose reads are inline asm (behind the builtin hipcc drains the LDS-DMA prefetch with vmcnt(0) in front of each), so
+        // the waits are ours too: counted lgkmcnt, naming every destination so that no consumer is scheduled above the wait.
+        bf16x4 va[2][NB][2][2];
+        const int vslot = vbase + slot * G::SLOTB;
+        auto vreads = [&](int db, bf16x4 (&f)[NB][2][2]) __attribute__((always_inline)) {
+            const int ad = vslot ^ (db << 6);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[blk][jj][0]) : "v"(ad), "i"((32 * blk + 16 * jj) * G::ROWB));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[blk][jj][1]) : "v"(ad), "i"((32 * blk + 16 * jj + 8) * G::ROWB));
+                }
+        };
+        if (SA32_VEARLY) vreads(0, va[0]);
+
+        // ---- masks (wave-uniform branches: ordinary tiles run none of this)
+        if (mixed) {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const uint32_t w = (blk ? vhi : vlo) >> (4 * hi);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[blk][r] = ((w >> kreg(r)) & 1u) ? s[blk][r] : -INFINITY;
+            }
+        }
+        if (CAUSAL) {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const int k0 = j * G::KT + 32 * blk;
+                if (k0 + 31 > t0 + a.P) {                               // the diagonal crosses this block (wave-uniform)
+                    const int c = trow + a.P - k0 - 4 * hi;             // key kreg(r) + 4 hi of the block is visible iff kreg(r) <= c
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[blk][r] = (kreg(r) <= c) ? s[blk][r] : -INFINITY;
+                }
+            }
+        }
+#if !(SA32_ABLATE & 4)
+        // ---- online softmax (log2 domain), one query row per lane pair
+        float tm = s[0][0];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tm = fmaxf(tm, s[blk][r]);
+        {
+            float lo, up;
+            swap32(tm, lo, up);
+            tm = fmaxf(lo, up);
+        }
+        const float tm2 = tm * LOG2E;
+        if (__builtin_amdgcn_ballot_w64(tm2 > m2 + SA32_THR) != 0ull) {
+            const float mn = fmaxf(m2, tm2);
+            const float alpha = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m2 - mn);
+            m2 = mn;
+            lsum *= alpha;
+#pragma unroll
+            for (int db = 0; db < G::NDB; ++db) o[db] *= alpha;
+        }
+        const float nms = (m2 == -INFINITY) ? 0.f : -m2;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[blk][r], LOG2E, nms));
+                s[blk][r] = p;
+                ps[r & 3] += p;
+            }
+        lsum += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+#endif
+        bf16x8 pf[NB][2];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                f32x8 t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = s[blk][8 * jj + e];
+                pf[blk][jj] = __builtin_convertvector(t, bf16x8);
+            }
+        if (!SA32_VEARLY) vreads(0, va[0]);
+#pragma unroll
+        for (int db = 0; db < G::NDB; ++db) {
+            bf16x4 (&f)[NB][2][2] = va[db & 1];
+            if (db + 1 < G::NDB) {
+                vreads(db + 1, va[(db + 1) & 1]);
+                if (NB == 2) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]));
+                else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]));
+            } else {
+                if (NB == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]));
+            }
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const bf16x4 x = f[blk][jj][0], y = f[blk][jj][1];
+                    const bf16x8 vf = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+                    o[db] = mma32(vf, pf[blk][jj], o[db]);
+                }
+        }
+    };
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int jt = wave + 4 * i, s = jt * G::KT + lane;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(s < Tk && (nomask || vraw[i] != 0));
+        if (lane == 0 && jt < nkt) vbits[jt] = m;
+    }
+    for (int jt = wave + 16; jt < nkt; jt += 4) {                       // sequences beyond 1024 keys: the remaining tiles, one by one
+        const int s = jt * G::KT + lane;
+        const uint8_t vbyte = valid_row ? valid_row[min(s, Tk - 1)] : (uint8_t)1;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(s < Tk && vbyte != 0);
+        if (lane == 0) vbits[jt] = m;
+    }
+    // "Q is complete": a load issued before a loop and first used inside it stays pending in hipcc's waitcnt scoreboard at the loop
+    // header -- every iteration would wait (vmcnt) for the LDS-DMA prefetch just issued as well
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks) asm volatile("" ::"v"(qf[ks]));
+    SA32_BARRIER();                                                     // the valid words are visible
+    uint64_t vm = vbits[0];
+    int slot = 0, islot = PD % G::NS;
+    for (int j = 0; j < ((SA32_ABLATE & 16) ? 0 : nkt); ++j) {
+        // tile j has landed (this wave's pieces: all but the NP * (tiles still in flight behind it) youngest loads), then everybody's
+        if (PD >= 2 && j + 1 < nkt) {
+            if (G::NP == 4) SA32_VMCNT(4); else SA32_VMCNT(8);
+        } else {
+            SA32_VMCNT(0);
+        }
+        if (!(SA32_ABLATE & 2)) SA32_BARRIER();
+        if (j + PD < nkt && !(SA32_ABLATE & 1)) issue(j + PD, islot);
+        const uint64_t vnext = vbits[min(j + 1, nkt - 1)];
+        const uint32_t vlo = __builtin_amdgcn_readfirstlane((uint32_t)vm), vhi = __builtin_amdgcn_readfirstlane((uint32_t)(vm >> 32));
+        if (j <= jlast && (vlo | vhi) != 0u && !(SA32_ABLATE & 8)) {
+            const bool mixed = (vlo & vhi) != 0xffffffffu;
+            // (a one-block variant of the body for a diagonal tile whose second 32 keys lie above the whole wave would save 5 % of
+            // the block steps at T = 640; as a second inlined body it costs 42 VGPRs and 48 accumulator copies per tile)
+            body(std::integral_constant<int, 2>(), j, vlo, vhi, mixed, slot);
+        }
+        vm = vnext;
+        slot = (slot + 1 == G::NS) ? 0 : slot + 1;
+        islot = (islot + 1 == G::NS) ? 0 : islot + 1;
+    }
+
+    // ---- epilogue: fold the lane pair's row sums, normalise, store O (16-byte stores after a v_permlane32_swap) and the LSE
+    {
+        float lo, up;
+        swap32(lsum, lo, up);
+        lsum = lo + up;
+    }
+    const float inv = __builtin_amdgcn_rcpf(lsum);
+    const uint32_t orow = wave_active ? (uint32_t)trow * ldoB : OOB;
+#pragma unroll
+    for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+            f32x4 ga, gb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ga[r] = o[db][4 * c + r] * inv;
+                gb[r] = o[db][4 * c + 4 + r] * inv;
+            }
+            u32x2 ua = __builtin_bit_cast(u32x2, __builtin_convertvector(ga, bf16x4)), ub = __builtin_bit_cast(u32x2, __builtin_convertvector(gb, bf16x4));
+            uint32_t a0 = ua[0], a1 = ua[1], b0 = ub[0], b1 = ub[1];
+            swap32_u32(a0, b0);
+            swap32_u32(a1, b1);
+            const u32x4 val = {a0, a1, b0, b1};
+            __builtin_amdgcn_raw_buffer_store_b128(val, ro, orow + (uint32_t)(32 * db + 8 * (c + hi)) * 2u, 0, ATTN_STORE_AUX);
+        }
+    if (a.lse && hi == 0 && trow < Tq) a.lse[(size_t)bh * a.T + trow] = (m2 + __builtin_amdgcn_logf(lsum)) * LN2;
+}
+
+template <int D, bool CAUSAL> int launch_fwd(const SA32Args& a, int nblocks, hipStream_t st) {
+    typedef G32<D> G;
+    auto kern = sa32_fwd_kernel<D, CAUSAL>;
+    static bool configured = false;                 // per instantiation
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute(sa32_fwd): %s", hipGetErrorString(e));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), G::LDS, st, a);
+    MMGL_CHECK_LAUNCH("sa32_fwd");
+    return MMGL_OK;
+}
+
+}  // namespace
+
+bool sa32_supported(int D, int Tk) { return (D == 64 || D == 128) && Tk <= 64 * 64; }
+
+int sa32_fwd(const void* q, const void* k, const void* v, const uint8_t* valid, void* out, float* lse, int B, int H, int T, int P,
+             int D, int ldq, int ldk, hipStream_t st) {
+    SA32Args a{};
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.valid = valid; a.out = (bf16*)out; a.lse = lse; a.cu = nullptr;
+    a.B = B; a.H = H; a.T = T; a.P = P; a.nqb = cdiv(T, 128); a.ldq = ldq; a.ldk = ldk; a.ldo = H * D; a.q_rows = T;
+    const int nblocks = B * H * a.nqb;
+    return D == 64 ? launch_fwd<64, true>(a, nblocks, st) : launch_fwd<128, true>(a, nblocks, st);
+}
+
+int sa32_enc_fwd(const void* q, const void* k, const void* v, const int* cu, void* out, int nseq, int H, int D, int ld_in, int ld_out,
+                 int max_len, int q_rows, hipStream_t st) {
+    SA32Args a{};
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.valid = nullptr; a.out = (bf16*)out; a.lse = nullptr; a.cu = cu;
+    a.B = nseq; a.H = H; a.T = max_len; a.P = 0; a.nqb = cdiv(max_len < q_rows ? max_len : q_rows, 128); a.ldq = ld_in; a.ldk = ld_in;
+    a.ldo = ld_out; a.q_rows = q_rows;
+    const int nblocks = nseq * H * a.nqb;
+    return D == 64 ? launch_fwd<64, false>(a, nblocks, st) : launch_fwd<128, false>(a, nblocks, st);
+}

@@ -11,7 +11,7 @@ from mmgl_amd import _lib  # noqa: E402
 from mmgl_amd._lib import ptr, stream_ptr  # noqa: E402
 
 
-def run(B, H=32, T=640, D=64, dtype=torch.bfloat16, iters=50):
+def run(B, H=32, T=640, D=64, dtype=torch.bfloat16, iters=50, masked=True):
     L = _lib.lib()
     d = H * D
     q = (torch.randn(B, T, d, device="cuda") * 0.2).to(dtype)
@@ -19,7 +19,8 @@ def run(B, H=32, T=640, D=64, dtype=torch.bfloat16, iters=50):
     v = torch.randn(B, T, d, device="cuda").to(dtype)
     w = torch.randn(B, T, d, device="cuda").to(dtype)
     valid = torch.ones(B, T, dtype=torch.uint8, device="cuda")
-    valid[:, 400:512] = 0
+    if masked:
+        valid[:, 400:512] = 0
     out = torch.empty_like(q)
     lse = torch.empty(B, H, T, dtype=torch.float32, device="cuda")
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -45,9 +46,12 @@ def run(B, H=32, T=640, D=64, dtype=torch.bfloat16, iters=50):
     tf = ev[0].elapsed_time(ev[1]) / iters * 1e-3
     tb = ev[2].elapsed_time(ev[3]) / iters * 1e-3
     fl = 4.0 * B * T * T * d / 2            # causal half
-    print(f"B={B:3d} H={H} T={T} D={D} {str(dtype)[6:]:9s} fwd {tf*1e6:8.1f} us {fl/tf/1e12:6.1f} TF(causal) | bwd {tb*1e6:8.1f} us {2.5*fl/tb/1e12:6.1f} TF", flush=True)
+    print(f"B={B:3d} H={H} T={T} D={D} {str(dtype)[6:]:9s} {'masked' if masked else 'dense ':6s} fwd {tf*1e6:8.1f} us {fl/tf/1e12:6.1f} TF(causal) | bwd {tb*1e6:8.1f} us {2.5*fl/tb/1e12:6.1f} TF", flush=True)
 
 
 if __name__ == "__main__":
     for B in [int(a) for a in sys.argv[1:]] or [8, 16]:
         run(B)
+        run(B, masked=False)
+    if os.environ.get("BENCH_SA_LLAMA"):
+        run(8, H=32, T=2176, D=128, masked=False)
