@@ -1000,16 +1000,18 @@ int sa_fwd(const void* q, const void* k, const void* v, const uint8_t* valid, vo
 
 template <typename T, int D>
 int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, const uint8_t* valid,
-           void* dq, void* dk, void* dv, float* delta, int B, int H, int T_, int ldq, int ldg, int P, int ldk, int ldgk, hipStream_t st) {
+           void* dq, void* dk, void* dv, float* delta, int B, int H, int T_, int ldq, int ldg, int P, int ldk, int ldgk, hipStream_t st,
+           bool dkv_only = false) {
     // ldq / ldg: row strides of q / dq; ldk / ldgk: of k, v / dk, dv ([B, P + T] rows); P prefix keys (0 = plain causal attention)
-    {
+    // dkv_only: delta and dq have been produced already (selfattn32.hip's first backward kernel)
+    if (!dkv_only) {
         const size_t total = (size_t)B * T_ * H * (D / 8);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL((rowdot_kernel<T, D>), dim3(blocks), dim3(256), 0, st, (const T*)dout, (const T*)out, delta, B, H, T_);
         MMGL_CHECK_LAUNCH("selfattn_rowdot");
     }
-    {
+    if (!dkv_only) {
         typedef XC<T, D, 4, 2> C;
         const int QB = 4 * 16 * C::QT, nqb = cdiv(T_, QB);
         const size_t lds = 2 * (sizeof(T) * ((C::TIMG ? C::RMIMG : C::ROWIMG) + C::ROWIMG) + KT);
@@ -1156,6 +1158,16 @@ extern "C" int mmgl_selfattn_prefix_bwd(const void* dout, const void* q, const v
     MMGL_CHECK_ARG(workspace_bytes >= mmgl_selfattn_bwd_workspace(B, H, T), "mmgl_selfattn_prefix_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* delta = (float*)workspace;
+    if (dtype == MMGL_BF16 && use_sa32() && sa32_supported(D, T + P)) {
+        static const int parts = [] { const char* e = getenv("MMGL_SELFATTN_32_BWD"); return e ? atoi(e) : 3; }();     // A/B: 1 = dQ only, then the 16x16 dK / dV kernel
+        // head_dim 128: the 32-keys-per-wave dK / dV kernel needs 2 x 64 accumulator registers on top of K^T / V^T (64): it spills;
+        // the 16x16 kernel (32 keys per wave as two 16-key blocks) keeps that half of the backward pass
+        const int p = (D == 128) ? (parts & 1) : parts;
+        rc = sa32_bwd(dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, P, D, ld_q, ld_kv, ld_dq, ld_dkv, p, st);
+        if (rc || (p & 2)) return rc;
+        if (!(p & 1)) { SA_DISPATCH(sa_bwd, bf16, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_q, ld_dq, P, ld_kv, ld_dkv, st) }
+        SA_DISPATCH(sa_bwd, bf16, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_q, ld_dq, P, ld_kv, ld_dkv, st, true)
+    }
     if (dtype == MMGL_BF16) { SA_DISPATCH(sa_bwd, bf16, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_q, ld_dq, P, ld_kv, ld_dkv, st) }
     SA_DISPATCH(sa_bwd, float, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_q, ld_dq, P, ld_kv, ld_dkv, st)
 }

@@ -377,6 +377,463 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
     if (a.lse && hi == 0 && trow < Tq) a.lse[(size_t)bh * a.T + trow] = (m2 + __builtin_amdgcn_logf(lsum)) * LN2;
 }
 
+
+// ================================================================================================================== backward
+// Two kernels with the forward's skeleton (32x32x16 MFMAs, swapped products, LDS-DMA rings, tile classes from the valid words):
+//   sa32_bwd_dq_kernel   workgroup = 128 query rows, loop over key tiles: dQ, and delta = rowsum(dO * O) for the second kernel
+//   sa32_bwd_dkv_kernel  workgroup = 128 keys, loop over query tiles: dK, dV
+// Every tile of the backward pass is read row-wise (ds_read_b128 A-operand fragments) AND transposed (ds_read_b64_tr_b16), so the
+// ring tiles use one swizzle that is conflict-free for both: the 3 (4) row bits that the row-fragment read needs spread over
+// distinct slots, bit-reversed so that rows r and r + 2 (which share a bank half) land in different 64-byte quarters.
+template <int D> __device__ __forceinline__ int swz_u(int row) {
+    if (D == 64) { const int x = (row >> 1) & 7; return ((x & 1) << 2) | (x & 2) | (x >> 2); }
+    return ((row & 3) << 2) | ((row >> 2) & 3);
+}
+// lane base of the A-operand row fragment (row = lane & 31, 16-byte slot 2 ks + hi): address = base ^ (ks << 5)
+template <int D> __device__ __forceinline__ int rowfrag_base(int lane) {
+    const int row = lane & 31, hi = lane >> 5;
+    return row * G32<D>::ROWB + ((hi ^ swz_u<D>(row)) << 4);
+}
+// lane base of the transposed fragment read (see the forward kernel): second read of a fragment (rows + 8) = (base ^ TRX) + 8 rows
+template <int D> __device__ __forceinline__ int trfrag_base(int lane) {
+    const int i = lane & 15, gg = lane >> 4;
+    const int row = 4 * (gg >> 1) + (i >> 2);
+    return row * G32<D>::ROWB + (((2 * (gg & 1) + ((i & 3) >> 1)) ^ swz_u<D>(row)) << 4) + 8 * (i & 1);
+}
+template <int D> struct TRX { static constexpr int value = (D == 64) ? 16 : 32; };      // what swz_u(row + 8) flips
+
+struct SA32BwdArgs {
+    const bf16 *dout, *q, *k, *v, *out;
+    const float* lse;
+    const uint8_t* valid;
+    bf16 *dq, *dk, *dv;
+    float* delta;              // [B, H, T]: written by the dQ kernel, read by the dK / dV kernel
+    int B, H, T, P, nqb, nkb, ldq, ldk, ldg, ldgk;
+};
+
+// 16 transposed fragments' worth of reads for ONE 32-channel block: f[blk][jj][half]; rows 32 blk + 16 jj (+ 8) of the tile at `ad`
+#define SA32_TR_READ(dst, ad, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "i"(off))
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void sa32_bwd_dq_kernel(SA32BwdArgs a) {
+    typedef G32<D> G;
+    constexpr int NS = 2, PD = NS - 1;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int key = lane & 31, hi = lane >> 5;
+
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = vid / a.nqb, qblk = a.nqb - 1 - vid % a.nqb;
+    const int b = bh / a.H, h = bh % a.H;
+    const int Tq = a.T, Tk = a.T + a.P, HD = a.H * D;
+    const int t0 = qblk * 128 + wave * 32, trow = t0 + key;
+    const int nkt = (min(Tq, (qblk + 1) * 128) + a.P + G::KT - 1) / G::KT;
+
+    const uint32_t ldqB = (uint32_t)a.ldq * 2u, ldkB = (uint32_t)a.ldk * 2u, ldoB = (uint32_t)HD * 2u, ldgB = (uint32_t)a.ldg * 2u;
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(a.q + (size_t)b * Tq * a.ldq + h * D, (uint32_t)(Tq - 1) * ldqB + D * 2);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(a.k + (size_t)b * Tk * a.ldk + h * D, (uint32_t)(Tk - 1) * ldkB + D * 2);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(a.v + (size_t)b * Tk * a.ldk + h * D, (uint32_t)(Tk - 1) * ldkB + D * 2);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.dout + (size_t)b * Tq * HD + h * D, (uint32_t)(Tq - 1) * ldoB + D * 2);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.out + (size_t)b * Tq * HD + h * D, (uint32_t)(Tq - 1) * ldoB + D * 2);
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(a.dq + (size_t)b * Tq * a.ldg + h * D, (uint32_t)(Tq - 1) * ldgB + D * 2);
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(a.lse + (size_t)bh * Tq, (uint32_t)Tq * 4u);
+
+    uint64_t* vbits = (uint64_t*)(smem + NS * G::SLOTB);
+    const __amdgpu_buffer_rsrc_t rvalid = make_rsrc(a.valid + (size_t)b * Tk, (uint32_t)Tk);
+    uint8_t vraw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vraw[i] = __builtin_amdgcn_raw_buffer_load_b8(rvalid, (uint32_t)((wave + 4 * i) * G::KT + lane), 0, 0);
+    const float lraw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (uint32_t)trow * 4u, 0, 0));    // 0 past T
+
+    // Q^T, dO^T (B operands) and O (for delta): lane (row, hi) holds channels 16 ks + 8 hi .. + 7
+    bf16x8 qf[G::NKS], gf[G::NKS], of[G::NKS];
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks) {
+        const uint32_t c = (uint32_t)(16 * ks + 8 * hi) * 2u;
+        qf[ks] = buf_load8<bf16>(rq, (uint32_t)trow * ldqB + c);
+        gf[ks] = buf_load8<bf16>(rg, (uint32_t)trow * ldoB + c);
+        of[ks] = buf_load8<bf16>(ro, (uint32_t)trow * ldoB + c);
+    }
+    uint32_t tvoff;
+    {
+        const int row = G::RPP * wave + lane / G::LPR, sl = lane % G::LPR;
+        tvoff = (uint32_t)row * ldkB + (uint32_t)((sl ^ swz_u<D>(row)) << 4);
+    }
+    auto issue = [&](int j, int slot) __attribute__((always_inline)) {
+        char* base = smem + slot * G::SLOTB + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < G::PIECES / 4; ++i) {
+            const int soff = (int)((uint32_t)(j * G::KT + i * 4 * G::RPP) * ldkB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)(base + i * 4096), 16, tvoff, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(base + G::TILEB + i * 4096), 16, tvoff, soff, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < PD; ++j) issue(j, j);
+
+    const int lds0 = (int)(unsigned)(size_t)(lds_void*)smem;
+    const int rbase = rowfrag_base<D>(lane);
+    const int tbase = lds0 + trfrag_base<D>(lane);
+
+    // delta = rowsum(dO * O) of this lane pair's row; the dK / dV kernel reads it from the workspace
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) delta = fmaf((float)gf[ks][e], (float)of[ks][e], delta);
+    {
+        float lo, up;
+        swap32(delta, lo, up);
+        delta = lo + up;
+    }
+    if (hi == 0 && trow < Tq) a.delta[(size_t)bh * Tq + trow] = delta;
+    const float nlse2 = -lraw * LOG2E;
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int jt = wave + 4 * i, s = jt * G::KT + lane;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(s < Tk && vraw[i] != 0);
+        if (lane == 0 && jt < nkt) vbits[jt] = m;
+    }
+    for (int jt = wave + 16; jt < nkt; jt += 4) {
+        const int s = jt * G::KT + lane;
+        const uint8_t vbyte = a.valid[(size_t)b * Tk + min(s, Tk - 1)];
+        const uint64_t m = __builtin_amdgcn_ballot_w64(s < Tk && vbyte != 0);
+        if (lane == 0) vbits[jt] = m;
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks) asm volatile("" ::"v"(qf[ks]), "v"(gf[ks]));
+
+    f32x16 acc[G::NDB];
+#pragma unroll
+    for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+    const bool wave_active = t0 < Tq;
+    const int tl = t0 + 31 + a.P;
+    const int jlast = !wave_active ? -1 : min(nkt - 1, tl >> 6);
+
+    auto body = [&](int j, uint32_t vlo, uint32_t vhi, bool mixed, int slot) __attribute__((always_inline)) {
+        const char* Ks = smem + slot * G::SLOTB;
+        const char* Vs = Ks + G::TILEB;
+        bf16x8 dsf[2][2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < G::NKS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(Ks + blk * 32 * G::ROWB + (rbase ^ (ks << 5)));
+                const bf16x8 vf = *(const bf16x8*)(Vs + blk * 32 * G::ROWB + (rbase ^ (ks << 5)));
+                s = mma32(kf, qf[ks], s);
+                dp = mma32(vf, gf[ks], dp);
+            }
+            if (mixed) {
+                const uint32_t w = (blk ? vhi : vlo) >> (4 * hi);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = ((w >> kreg(r)) & 1u) ? s[r] : -INFINITY;
+            }
+            const int k0 = j * G::KT + 32 * blk;
+            if (k0 + 31 > t0 + a.P) {
+                const int c = trow + a.P - k0 - 4 * hi;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = (kreg(r) <= c) ? s[r] : -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, nlse2));
+                s[r] = p * (dp[r] - delta);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                f32x8 t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = s[8 * jj + e];
+                dsf[blk][jj] = __builtin_convertvector(t, bf16x8);
+            }
+        }
+        // dQ^T += K^T dS^T: K^T fragments by transposed reads of the same K tile, one 32-channel block at a time, two register sets
+        bf16x4 ka[2][2][2][2];
+        const int kslot = tbase + slot * G::SLOTB;
+        auto treads = [&](int db, bf16x4 (&f)[2][2][2]) __attribute__((always_inline)) {
+            const int ad0 = kslot ^ (db << 6), ad1 = ad0 ^ TRX<D>::value;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    SA32_TR_READ(f[blk][jj][0], ad0, (32 * blk + 16 * jj) * G::ROWB);
+                    SA32_TR_READ(f[blk][jj][1], ad1, (32 * blk + 16 * jj + 8) * G::ROWB);
+                }
+        };
+        treads(0, ka[0]);
+#pragma unroll
+        for (int db = 0; db < G::NDB; ++db) {
+            bf16x4 (&f)[2][2][2] = ka[db & 1];
+            if (db + 1 < G::NDB) {
+                treads(db + 1, ka[(db + 1) & 1]);
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]));
+            }
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const bf16x4 x = f[blk][jj][0], y = f[blk][jj][1];
+                    const bf16x8 kt = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+                    acc[db] = mma32(kt, dsf[blk][jj], acc[db]);
+                }
+        }
+    };
+
+    SA32_BARRIER();
+    uint64_t vm = vbits[0];
+    int slot = 0, islot = PD % NS;
+    for (int j = 0; j < nkt; ++j) {
+        SA32_VMCNT(0);                                                  // NS = 2: one tile in flight
+        SA32_BARRIER();
+        if (j + PD < nkt) issue(j + PD, islot);
+        const uint64_t vnext = vbits[min(j + 1, nkt - 1)];
+        const uint32_t vlo = __builtin_amdgcn_readfirstlane((uint32_t)vm), vhi = __builtin_amdgcn_readfirstlane((uint32_t)(vm >> 32));
+        if (j <= jlast && (vlo | vhi) != 0u) body(j, vlo, vhi, (vlo & vhi) != 0xffffffffu, slot);
+        vm = vnext;
+        slot = (slot + 1 == NS) ? 0 : slot + 1;
+        islot = (islot + 1 == NS) ? 0 : islot + 1;
+    }
+
+    const uint32_t orow = wave_active ? (uint32_t)trow * ldgB : OOB;
+#pragma unroll
+    for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+            f32x4 ga, gb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ga[r] = acc[db][4 * c + r];
+                gb[r] = acc[db][4 * c + 4 + r];
+            }
+            u32x2 ua = __builtin_bit_cast(u32x2, __builtin_convertvector(ga, bf16x4)), ub = __builtin_bit_cast(u32x2, __builtin_convertvector(gb, bf16x4));
+            uint32_t a0 = ua[0], a1 = ua[1], b0 = ub[0], b1 = ub[1];
+            swap32_u32(a0, b0);
+            swap32_u32(a1, b1);
+            const u32x4 val = {a0, a1, b0, b1};
+            __builtin_amdgcn_raw_buffer_store_b128(val, rd, orow + (uint32_t)(32 * db + 8 * (c + hi)) * 2u, 0, ATTN_STORE_AUX);
+        }
+}
+
+
+// dK, dV: workgroup = 128 keys of one (batch, head), wave = 32 keys; loop over 64-row query tiles from the first row that sees the
+// workgroup's keys to the last.  Per tile the ring slot holds Q and dO (row-major, swz_u) and the tile's lse / delta vectors.
+// Non-swapped products put the KEY on the lane: S = Q K^T (A = Q rows from LDS, B = K^T in registers) leaves P / dS in the
+// accumulators as [query (r, hi)][key = lane & 31] -- the B-operand layout of the contraction over queries -- and dV^T += dO^T P,
+// dK^T += Q^T dS take their A operands by transposed reads of the same dO / Q tiles.  The row statistics enter as the MFMA
+// C-input: with K and V NEGATED in registers the accumulators start at lse / delta (16-byte broadcast reads straight into the
+// accumulator registers) and end at lse - q.k and delta - dO.v, so p = exp2(-log2e * acc + key bias) and dS = -p * acc': the sign
+// of dS is folded into the final store of dK.  No row reductions, no per-element subtraction.
+template <int D> struct GB32 {
+    typedef G32<D> G;
+    static constexpr int SLOTB = 2 * G::TILEB + 1024;                    // Q tile, dO tile, lse[64], delta[64], padding
+    static constexpr int NS = 2;
+    static constexpr int LDS = NS * SLOTB;
+    static constexpr int NPB = 2 * G::PIECES / 4 + 2;                    // LDS-DMA instructions per wave and tile
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
+    typedef G32<D> G;
+    typedef GB32<D> GB;
+    constexpr int NS = GB::NS, PD = NS - 1;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int kl = lane & 31, hi = lane >> 5;
+
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = vid / a.nkb, kblk = vid % a.nkb;                      // low key blocks (most query tiles) first
+    const int b = bh / a.H, h = bh % a.H;
+    const int Tq = a.T, Tk = a.T + a.P, HD = a.H * D;
+    const int k0 = kblk * 128 + wave * 32, krow = k0 + kl;               // this lane's key
+    const int nqt = (Tq + 63) / 64;
+    const int i0 = max(kblk * 128 - a.P, 0) / 64;                        // first query tile with a row that sees key kblk * 128
+
+    const uint32_t ldqB = (uint32_t)a.ldq * 2u, ldkB = (uint32_t)a.ldk * 2u, ldoB = (uint32_t)HD * 2u, ldgB = (uint32_t)a.ldgk * 2u;
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(a.q + (size_t)b * Tq * a.ldq + h * D, (uint32_t)(Tq - 1) * ldqB + D * 2);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(a.k + (size_t)b * Tk * a.ldk + h * D, (uint32_t)(Tk - 1) * ldkB + D * 2);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(a.v + (size_t)b * Tk * a.ldk + h * D, (uint32_t)(Tk - 1) * ldkB + D * 2);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.dout + (size_t)b * Tq * HD + h * D, (uint32_t)(Tq - 1) * ldoB + D * 2);
+    const __amdgpu_buffer_rsrc_t rdk = make_rsrc(a.dk + (size_t)b * Tk * a.ldgk + h * D, (uint32_t)(Tk - 1) * ldgB + D * 2);
+    const __amdgpu_buffer_rsrc_t rdv = make_rsrc(a.dv + (size_t)b * Tk * a.ldgk + h * D, (uint32_t)(Tk - 1) * ldgB + D * 2);
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(a.lse + (size_t)bh * Tq, (uint32_t)Tq * 4u);
+    const __amdgpu_buffer_rsrc_t rdl = make_rsrc(a.delta + (size_t)bh * Tq, (uint32_t)Tq * 4u);
+    const __amdgpu_buffer_rsrc_t rvalid = make_rsrc(a.valid + (size_t)b * Tk, (uint32_t)Tk);
+
+    // K^T, V^T (B operands; lane = key): channels 16 ks + 8 hi .. + 7 of this lane's key row, sign flipped (see above)
+    const uint8_t kvraw = __builtin_amdgcn_raw_buffer_load_b8(rvalid, (uint32_t)krow, 0, 0);       // 0 past the last key
+    bf16x8 kf[G::NKS], vf[G::NKS];
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks) {
+        const uint32_t c = (uint32_t)krow * ldkB + (uint32_t)(16 * ks + 8 * hi) * 2u;
+        kf[ks] = buf_load8<bf16>(rk, c);
+        vf[ks] = buf_load8<bf16>(rv, c);
+    }
+    uint32_t qvoff, gvoff;
+    {
+        const int row = G::RPP * wave + lane / G::LPR, sl = lane % G::LPR;
+        const uint32_t sw = (uint32_t)((sl ^ swz_u<D>(row)) << 4);
+        qvoff = (uint32_t)row * ldqB + sw;
+        gvoff = (uint32_t)row * ldoB + sw;
+    }
+    auto issue = [&](int i, int slot) __attribute__((always_inline)) {
+        char* base = smem + slot * GB::SLOTB;
+#pragma unroll
+        for (int c = 0; c < G::PIECES / 4; ++c) {
+            const int r0 = i * 64 + c * 4 * G::RPP;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void*)(base + wave * 1024 + c * 4096), 16, qvoff, (int)((uint32_t)r0 * ldqB), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(base + G::TILEB + wave * 1024 + c * 4096), 16, gvoff, (int)((uint32_t)r0 * ldoB), 0, 0);
+        }
+        // the tile's 64 lse / delta values: every wave requests them (same bytes to the same place; keeps the vmcnt bookkeeping uniform)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_void*)(base + 2 * G::TILEB), 4, (uint32_t)lane * 4u, i * 256, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdl, (lds_void*)(base + 2 * G::TILEB + 256), 4, (uint32_t)lane * 4u, i * 256, 0, 0);
+    };
+    if (i0 < nqt) issue(i0, 0);
+
+    const int lds0 = (int)(unsigned)(size_t)(lds_void*)smem;
+    const int rbase = rowfrag_base<D>(lane);
+    const int tbase = lds0 + trfrag_base<D>(lane);
+
+    f32x16 dka[G::NDB], dva[G::NDB];
+#pragma unroll
+    for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dka[db][r] = 0.f; dva[db][r] = 0.f; }
+
+    // sign flip + "these registers are complete" (see the forward kernel: loads first used inside the loop)
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks) {
+        u32x4 x = __builtin_bit_cast(u32x4, kf[ks]), y = __builtin_bit_cast(u32x4, vf[ks]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] ^= 0x80008000u; y[e] ^= 0x80008000u; }
+        kf[ks] = __builtin_bit_cast(bf16x8, x);
+        vf[ks] = __builtin_bit_cast(bf16x8, y);
+        asm volatile("" ::"v"(kf[ks]), "v"(vf[ks]));
+    }
+    const float kbias = (krow < Tk && kvraw != 0) ? 0.f : -INFINITY;
+    const bool wave_has_keys = __builtin_amdgcn_ballot_w64(kbias == 0.f) != 0ull;     // a wave of masked / absent keys has dK = dV = 0
+
+    auto body = [&](int i, int slot) __attribute__((always_inline)) {
+        const char* Qs = smem + slot * GB::SLOTB;
+        const char* Gs = Qs + G::TILEB;
+        const char* St = Qs + 2 * G::TILEB;
+        bf16x8 pf[2][2], dsf[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 l4 = *(const f32x4*)(St + (32 * qb + 8 * c + 4 * hi) * 4);
+                const f32x4 d4 = *(const f32x4*)(St + 256 + (32 * qb + 8 * c + 4 * hi) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[4 * c + r] = l4[r]; dp[4 * c + r] = d4[r]; }
+            }
+#pragma unroll
+            for (int ks = 0; ks < G::NKS; ++ks) {
+                const bf16x8 qr = *(const bf16x8*)(Qs + qb * 32 * G::ROWB + (rbase ^ (ks << 5)));
+                const bf16x8 gr = *(const bf16x8*)(Gs + qb * 32 * G::ROWB + (rbase ^ (ks << 5)));
+                s = mma32(qr, kf[ks], s);
+                dp = mma32(gr, vf[ks], dp);
+            }
+            // s = lse - q.k, dp = delta - dO.v;  query of register r: 64 i + 32 qb + kreg(r) + 4 hi
+            const int q0 = i * 64 + 32 * qb;
+            const bool diag = q0 + a.P < k0 + 31;                        // some (query, key) pair of this block with key > query + P
+            const int c2 = krow - a.P - q0 - 4 * hi;                     // visible iff kreg(r) >= c2
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float e = fmaf(s[r], -LOG2E, kbias);
+                if (diag) e = (kreg(r) >= c2) ? e : -INFINITY;
+                const float p = __builtin_amdgcn_exp2f(e);
+                s[r] = p;
+                dp[r] = p * dp[r];                                       // = -dS
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                f32x8 t, u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { t[e] = s[8 * jj + e]; u[e] = dp[8 * jj + e]; }
+                pf[qb][jj] = __builtin_convertvector(t, bf16x8);
+                dsf[qb][jj] = __builtin_convertvector(u, bf16x8);
+            }
+        }
+        // dV^T += dO^T P, (-dK^T) += Q^T (-dS): transposed reads of the dO / Q tiles, one 32-channel block of one operand at a time
+        bf16x4 fa[2][2][2][2];
+        const int qslot = tbase + slot * GB::SLOTB, gslot = qslot + G::TILEB;
+        auto treads = [&](int step, bf16x4 (&f)[2][2][2]) __attribute__((always_inline)) {     // step = 2 db + (0: dO, 1: Q)
+            const int ad0 = ((step & 1) ? qslot : gslot) ^ ((step >> 1) << 6), ad1 = ad0 ^ TRX<D>::value;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    SA32_TR_READ(f[qb][jj][0], ad0, (32 * qb + 16 * jj) * G::ROWB);
+                    SA32_TR_READ(f[qb][jj][1], ad1, (32 * qb + 16 * jj + 8) * G::ROWB);
+                }
+        };
+        treads(0, fa[0]);
+#pragma unroll
+        for (int step = 0; step < 2 * G::NDB; ++step) {
+            bf16x4 (&f)[2][2][2] = fa[step & 1];
+            if (step + 1 < 2 * G::NDB) {
+                treads(step + 1, fa[(step + 1) & 1]);
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]));
+            }
+            const int db = step >> 1;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const bf16x4 x = f[qb][jj][0], y = f[qb][jj][1];
+                    const bf16x8 tf = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+                    if (step & 1) dka[db] = mma32(tf, dsf[qb][jj], dka[db]);
+                    else dva[db] = mma32(tf, pf[qb][jj], dva[db]);
+                }
+        }
+    };
+
+    int slot = 0;
+    for (int i = i0; i < nqt; ++i) {
+        SA32_VMCNT(0);                                                  // NS = 2: one tile in flight
+        SA32_BARRIER();
+        if (i + 1 < nqt) issue(i + 1, slot ^ 1);
+        // this wave's keys are seen by some row of the tile iff its first key k0 <= last row + P
+        if (wave_has_keys && k0 <= i * 64 + 63 + a.P) body(i, slot);
+        slot ^= 1;
+    }
+
+    // ---- epilogue: dK = -acc, dV rows (lane = key row: the forward kernel's output store)
+    const uint32_t orow = (krow < Tk) ? (uint32_t)krow * ldgB : OOB;
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+        for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+            for (int c = 0; c < 4; c += 2) {
+                f32x4 ga, gb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ga[r] = which ? dva[db][4 * c + r] : -dka[db][4 * c + r];
+                    gb[r] = which ? dva[db][4 * c + 4 + r] : -dka[db][4 * c + 4 + r];
+                }
+                u32x2 ua = __builtin_bit_cast(u32x2, __builtin_convertvector(ga, bf16x4)), ub = __builtin_bit_cast(u32x2, __builtin_convertvector(gb, bf16x4));
+                uint32_t a0 = ua[0], a1 = ua[1], b0 = ub[0], b1 = ub[1];
+                swap32_u32(a0, b0);
+                swap32_u32(a1, b1);
+                const u32x4 val = {a0, a1, b0, b1};
+                __builtin_amdgcn_raw_buffer_store_b128(val, which ? rdv : rdk, orow + (uint32_t)(32 * db + 8 * (c + hi)) * 2u, 0, ATTN_STORE_AUX);
+            }
+}
+
 template <int D, bool CAUSAL> int launch_fwd(const SA32Args& a, int nblocks, hipStream_t st) {
     typedef G32<D> G;
     auto kern = sa32_fwd_kernel<D, CAUSAL>;
@@ -388,6 +845,35 @@ template <int D, bool CAUSAL> int launch_fwd(const SA32Args& a, int nblocks, hip
     }
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), G::LDS, st, a);
     MMGL_CHECK_LAUNCH("sa32_fwd");
+    return MMGL_OK;
+}
+
+template <int D> int launch_bwd_dq(const SA32BwdArgs& a, hipStream_t st) {
+    typedef G32<D> G;
+    constexpr int LDS = 2 * G::SLOTB + G::MAXT * 8;
+    auto kern = sa32_bwd_dq_kernel<D>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute(sa32_bwd_dq): %s", hipGetErrorString(e));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.B * a.H * a.nqb), dim3(256), LDS, st, a);
+    MMGL_CHECK_LAUNCH("sa32_bwd_dq");
+    return MMGL_OK;
+}
+
+template <int D> int launch_bwd_dkv(const SA32BwdArgs& a, hipStream_t st) {
+    typedef GB32<D> GB;
+    auto kern = sa32_bwd_dkv_kernel<D>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GB::LDS);
+        if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute(sa32_bwd_dkv): %s", hipGetErrorString(e));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.B * a.H * a.nkb), dim3(256), GB::LDS, st, a);
+    MMGL_CHECK_LAUNCH("sa32_bwd_dkv");
     return MMGL_OK;
 }
 
@@ -412,4 +898,20 @@ int sa32_enc_fwd(const void* q, const void* k, const void* v, const int* cu, voi
     a.ldo = ld_out; a.q_rows = q_rows;
     const int nblocks = nseq * H * a.nqb;
     return D == 64 ? launch_fwd<64, false>(a, nblocks, st) : launch_fwd<128, false>(a, nblocks, st);
+}
+
+int sa32_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, const uint8_t* valid,
+             void* dq, void* dk, void* dv, float* delta, int B, int H, int T, int P, int D, int ldq, int ldk, int ldg, int ldgk, int parts,
+             hipStream_t st) {
+    SA32BwdArgs a{};
+    a.dout = (const bf16*)dout; a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (const bf16*)out; a.lse = lse;
+    a.valid = valid; a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.delta = delta;
+    a.B = B; a.H = H; a.T = T; a.P = P; a.nqb = cdiv(T, 128); a.nkb = cdiv(T + P, 128); a.ldq = ldq; a.ldk = ldk; a.ldg = ldg; a.ldgk = ldgk;
+    int rc = MMGL_OK;
+    if (parts & 1) rc = D == 64 ? launch_bwd_dq<64>(a, st) : launch_bwd_dq<128>(a, st);
+    if (rc == MMGL_OK && (parts & 2)) {
+        if (D != 64) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "sa32_bwd: the dK / dV kernel covers head_dim 64 only");
+        rc = launch_bwd_dkv<64>(a, st);
+    }
+    return rc;
 }
