@@ -288,9 +288,18 @@ def main():
     roof_name = "mmgl_gemm_nt" if cfg["kind"] == "lora" else "mmgl_xattn_fwd"
 
     n_steps_run = [0]
+    last_meter = [0.0]
+
+    # the trainer's step (reference run_generation.py:466-485; mmgl_amd train_loop): besides the token loss that is differentiated,
+    # the logits of the summary positions, their cross-entropy for the running meter, and its .item() -- a host sync -- every step
+    lin = cfg["lin"]
+    summary = slice(lin, T - 1)
 
     def step():
-        out = model(**batch)
+        out = model(**batch, logits_slice=summary)
+        lg = out.logits.detach()
+        meter = torch.nn.functional.cross_entropy(lg.reshape(-1, lg.size(-1)).float(), batch["labels"][..., lin + 1:].reshape(-1), ignore_index=1).item()
+        last_meter[0] = meter
         out.loss.backward()
         engine.finish_backward()
         engine.step()

@@ -124,12 +124,20 @@ class DataParallelEngine:
             self.buckets[-1:] = [dict(start=last["start"], end=mid, members=head, pending=len(head), work=None),
                                  dict(start=mid, end=last["end"], members=rest, pending=len(rest), work=None)]
         self._bucket_of = {}
-        for b in self.buckets:
+        for bi, b in enumerate(self.buckets):
+            b["idx"] = bi
             for i in b["members"]:
                 self._bucket_of[i] = b
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
         self.exchange_bytes = 0
+        # Collectives must be issued in the same order on every rank (RCCL matches them by issue order, not by buffer): the order
+        # is the order in which buckets fill, i.e. autograd's execution order of one graph -- identical by construction, and
+        # CHECKED on the first exchange of a run (and on every exchange under MMGL_DDP_CHECK_ORDER=1): see finish_backward
+        self.launch_order: List[int] = []
+        self._order_checked = False
+        import os
+        self._always_check_order = os.environ.get("MMGL_DDP_CHECK_ORDER", "0") == "1"
 
     # ---------------------------------------------------------------------------------- gradient exchange
     def _make_hook(self, i):
@@ -143,9 +151,25 @@ class DataParallelEngine:
             b = self._bucket_of[i]
             b["pending"] -= 1
             if b["pending"] == 0 and self.sync and self.world > 1:
-                b["work"] = dist.all_reduce(self.flat_grad[b["start"]:b["end"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                self.exchange_bytes += (b["end"] - b["start"]) * self.flat_grad.element_size()
+                self._launch(b)
         return hook
+
+    def _launch(self, b):
+        b["work"] = dist.all_reduce(self.flat_grad[b["start"]:b["end"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self.exchange_bytes += (b["end"] - b["start"]) * self.flat_grad.element_size()
+        self.launch_order.append(b["idx"])
+
+    def _check_launch_order(self):
+        """Every rank must have issued its bucket all-reduces in the same order.  One tiny all-gather, after the exchange."""
+        n = len(self.buckets)
+        mine = torch.tensor((self.launch_order + [-1] * n)[:n], dtype=torch.int64, device=self.device)
+        both = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(both, mine, group=self.pg)
+        orders = [t.tolist() for t in both]
+        if any(o != orders[0] for o in orders[1:]):
+            raise RuntimeError(f"DataParallelEngine: bucket all-reduces were issued in different orders across ranks: {orders} "
+                               "(the ranks ran different autograd graphs: a parameter unused on one rank, data-dependent control flow)")
+        self._order_checked = True
 
     def finish_backward(self):
         """Call after loss.backward(): waits for the bucket all-reduces (if this was a sync step) and re-arms the hooks.
@@ -154,10 +178,12 @@ class DataParallelEngine:
         if self.sync and self.world > 1:
             for b in self.buckets:
                 if b["work"] is None:
-                    b["work"] = dist.all_reduce(self.flat_grad[b["start"]:b["end"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                    self.exchange_bytes += (b["end"] - b["start"]) * self.flat_grad.element_size()
+                    self._launch(b)
             for b in self.buckets:
                 b["work"].wait()
+            if not self._order_checked or self._always_check_order:
+                self._check_launch_order()
+        self.launch_order = []
         for b in self.buckets:
             b["pending"], b["work"] = len(b["members"]), None
 

@@ -248,6 +248,11 @@ def _summary_slices(args, logits, labels):
     return lg, lb
 
 
+def _takes_logits_slice(model):
+    from ..model.modelling_cross_attention import CrossAttentionModel
+    return isinstance(model, CrossAttentionModel)
+
+
 def _host_meta(model, batch):
     """Host-side facts about a collated batch (which neighbor slots are real, how long each neighbor text is) for models that
     take them (`CrossAttentionModel.forward(host_meta=)`): the forward pass then never synchronises with the device."""
@@ -285,7 +290,7 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
     for i, batch in enumerate(train_loader):
         data_time.update(time.time() - end)
         extra = _host_meta(model, batch)               # read off the batch while it is still in host memory
-        sliced = args.decoder_only and (bool(extra) or _is_opt_self_attention(model))
+        sliced = args.decoder_only and (_takes_logits_slice(model) or _is_opt_self_attention(model))
         if sliced:                                     # the running summary loss below reads positions L_in .. T-2 only: the training
             # step then never builds the [B, T, V] logits (explicit stop: SelfAttentionModel appends neighbor tokens after position T-1)
             extra["logits_slice"] = slice(args.max_input_length, batch["input_ids"].shape[1] - 1)
@@ -418,17 +423,36 @@ def save_checkpoint(path, model, engine, scheduler, epoch, acc1):
     torch.save(state, path)
 
 
-def load_checkpoint(path, model, engine, scheduler, map_location):
-    # tensors + plain containers only: never unpickle arbitrary objects from a checkpoint file
-    with torch.serialization.safe_globals([OrderedDict]):
-        ck = torch.load(path, map_location=map_location, weights_only=True)
+def load_checkpoint(path, model, engine, scheduler, map_location, trust=None):
+    """Checkpoints written by save_checkpoint hold tensors and plain containers only and load through torch's weights-only
+    unpickler.  The REFERENCE's checkpoints (:402-416) do not: `GradualWarmupScheduler.state_dict()` keeps its `after_scheduler`
+    -- a pickled StepLR object, which carries the optimizer -- and the weights-only unpickler rejects that by design.  They load
+    with `trust=True` (or MMGL_TRUST_CHECKPOINT=1): the file is then unpickled the way the reference itself loads it (:340,
+    arbitrary code in the file WILL run), the StepLR object is dropped and its call count (`last_epoch`) taken over; the
+    optimizer state is matched by parameter name (DataParallelEngine.load_state_dict)."""
+    import pickle
+    if trust is None:
+        trust = os.environ.get("MMGL_TRUST_CHECKPOINT", "0") == "1"
+    try:
+        with torch.serialization.safe_globals([OrderedDict]):
+            ck = torch.load(path, map_location=map_location, weights_only=True)
+    except pickle.UnpicklingError as e:
+        if not trust:
+            raise RuntimeError(
+                f"{path}: not a tensors-and-plain-containers checkpoint ({str(e).splitlines()[0]}).  A checkpoint written by the "
+                "reference embeds pickled scheduler / optimizer objects; if you trust the file, load it with "
+                "MMGL_TRUST_CHECKPOINT=1 (load_checkpoint(..., trust=True))") from e
+        ck = torch.load(path, map_location=map_location, weights_only=False)
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ck["state_dict"].items()}
     model.load_state_dict(sd, strict=False)
     engine.sync_master_from_params()
     if "optimizer" in ck:
         engine.load_state_dict(ck["optimizer"])
     if scheduler is not None and "scheduler" in ck:
-        scheduler.load_state_dict(ck["scheduler"])
+        sch = ck["scheduler"]
+        if not isinstance(sch, dict):
+            sch = sch.state_dict()
+        scheduler.load_state_dict({k: v for k, v in sch.items() if k != "after_scheduler"})
     return ck
 
 

@@ -721,7 +721,8 @@ class _LMHeadCrossEntropy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         (dh,) = ctx.saved_tensors
-        return (dh * dloss.to(dh.dtype)).view(ctx.shape), None, None, None, None
+        # scale in fp32: 1 / grad_accumulation_steps rounded to bf16 first would bias every hidden gradient by up to 0.4 %
+        return (dh.float() * dloss.float()).to(dh.dtype).view(ctx.shape), None, None, None, None
 
 
 def lm_head_cross_entropy(hidden, weight, labels, ignore_index=-100, chunk_rows=8192):
@@ -1027,7 +1028,7 @@ class _RopeQK(torch.autograd.Function):
     def backward(ctx, dqkv):
         (cos_sin,) = ctx.saved_tensors
         T, H, D = ctx.meta
-        dqkv = dqkv.contiguous()
+        dqkv = dqkv.clone(memory_format=torch.contiguous_format)        # autograd owns the incoming buffer: rotate a copy, never in place
         rows = dqkv.numel() // dqkv.shape[-1]
         _lib.call("mmgl_rope_inplace", dict(bytes=2.0 * rows * (2 * dqkv.shape[-1] // 3) * dqkv.element_size()), ptr(dqkv), ptr(cos_sin), rows, T, H, D,
                   dqkv.shape[-1], 2, 1, dtype_code(dqkv), stream_ptr())

@@ -183,8 +183,8 @@ def test_lm_head_cross_entropy_fused_equals_unfused(M, d, V, chunk):
 
 
 def test_training_step_does_not_build_logits():
-    """MPTForCausalLM in train mode with a frozen head returns loss without .logits (peak memory stays below one full logits
-    tensor); `logits_slice` returns just those positions; eval keeps the reference contract."""
+    """MPTForCausalLM in train mode with a frozen head: the default is the reference's contract (.logits [B, T, V]); with
+    return_logits=False the step returns the loss without building them; `logits_slice` returns just those positions."""
     from helpers import mpt_args, tiny_opt_config
     from mmgl_amd.model.modelling_cross_attention import MPTConfig, MPTForCausalLM
     torch.manual_seed(0)
@@ -195,7 +195,8 @@ def test_training_step_does_not_build_logits():
     nv = torch.ones(2, 6, dtype=torch.bool, device="cuda")
     kw = dict(input_ids=ids, attention_mask=am, labels=ids, neighbor_embeds=ne, neighbor_attention_mask=nv)
     lm.train()
-    o = lm(**kw)
+    assert lm(**kw).logits.shape == (2, 24, 128)
+    o = lm(**kw, return_logits=False)
     assert o.logits is None and o.loss.requires_grad
     o.loss.backward()
     assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for n, p in lm.named_parameters() if "neighbor_layers" in n)

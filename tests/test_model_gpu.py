@@ -283,13 +283,21 @@ def test_full_size_opt_1_3b_step_loss_matches_cpu_oracle():
         L = b["neighbor_input_ids"].shape[-1]
         tl = model.text_model(input_ids=b["neighbor_input_ids"].reshape(-1, L), attention_mask=b["neighbor_attention_mask"].reshape(-1, L)).last_hidden_state
         vp = model.visual_model(b["neighbor_images"].reshape(-1, 3, 224, 224)).pooler_output
-    _, ref_loss = wrapper_ref.cross_attention_model_forward(sd, ocfg, b, tl, vp, "all", 4)
+    ref_logits, ref_loss = wrapper_ref.cross_attention_model_forward(sd, ocfg, b, tl, vp, "all", 4)
     ref_loss.backward()
+    ref_logits = ref_logits.detach()
     # HIP path, fp32 first (same arithmetic as the oracle up to summation order): tight check of the gradients
     dev = model.cuda()
     out32 = dev(**{k: v.cuda() for k, v in b.items()})
     out32.loss.backward()
     assert abs(float(out32.loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss)), (float(out32.loss), float(ref_loss))
+    # BASELINE.json's acceptance: "within 1e-3 relative fp32 on logits" (reference lm_head, modelling_cross_attention.py:826) -- the
+    # whole [1, 640, 50272] tensor, and separately the summary positions evaluate_loop scores (run_generation.py:584-591)
+    L_in = cfg["lin"]
+    e_all = assert_close(out32.logits.float().cpu(), ref_logits, 1e-3, "fp32 logits, all positions")
+    e_sum = assert_close(out32.logits[:, L_in:-1].float().cpu(), ref_logits[:, L_in:-1], 1e-3, "fp32 logits, summary positions")
+    agree = (out32.logits[:, L_in:-1].argmax(-1).cpu() == ref_logits[:, L_in:-1].argmax(-1)).float().mean().item()
+    print(f"   fp32 logits vs CPU oracle: rel err {e_all:.2e} (all), {e_sum:.2e} (summary positions); argmax agreement {agree:.4f}")
     p32 = dict(dev.named_parameters())
     for k in gates:
         g, r = float(p32[k].grad), float(sd[k].grad)
@@ -306,9 +314,18 @@ def test_full_size_opt_1_3b_step_loss_matches_cpu_oracle():
     assert torch.isfinite(out.loss)
     assert abs(float(out.loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
     params = dict(dev.named_parameters())
-    for k in gates:                                        # scalar gates: the gradient through everything above them
-        g, r = float(params[k].grad), float(sd[k].grad)
+    # Scalar gates: d loss / d gate = sum over the sample's 640 x 2048 activations of (upstream gradient x block output) -- 1.3 M signed
+    # bf16 products that cancel down to 1e-4 .. 1e-2.  The bf16 rounding noise of such a sum is an ABSOLUTE floor (measured: 1e-5 ..
+    # 5e-4, largest at the lowest layer, whose upstream gradient has crossed 24 + 3 layers in bf16), so the error is judged against
+    # the size of the gate-gradient vector, not gate by gate: the round-2 "22 %" was 6e-5 of error on a 1.3e-4 gradient.
+    # Measured (round 3): 3.5 % norm-wise; per gate <= 14 % of its own value once the 1e-4 floor is taken off.
+    gg = torch.tensor([float(params[k].grad) for k in gates])
+    rr = torch.tensor([float(sd[k].grad) for k in gates])
+    for k, g, r in zip(gates, gg.tolist(), rr.tolist()):
         print(f"   d loss / d {k}: {g:+.5e} vs {r:+.5e}")
-        assert abs(g - r) <= 0.35 * abs(r) + 2e-4, (k, g, r)      # a sum of 1.3 M signed bf16 products: loose by nature (fp32 above is tight)
+        assert abs(g - r) <= 0.18 * abs(r) + 1e-4, (k, g, r)
+    nerr = float((gg - rr).norm() / rr.norm())
+    print(f"   bf16 gate gradients, norm-wise relative error {nerr:.4f}")
+    assert nerr <= 0.06, nerr
     for k in ("text_embeddings.bias", "visual_embeddings.bias"):
         assert_close(params[k].grad.float().cpu(), sd[k].grad, 0.1, f"d {k}")

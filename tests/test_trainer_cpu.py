@@ -35,6 +35,42 @@ def test_t5_section_only_raw_trains_and_checkpoints(tmp_path):
     assert not any(".text_model" in k or ".visual_model" in k for k in ck["state_dict"])
 
 
+def test_load_checkpoint_reference_format_needs_opt_in(tmp_path):
+    """A checkpoint in the reference's layout (run_generation.py:402-416): `scheduler` = GradualWarmupScheduler.state_dict(), which
+    embeds the pickled StepLR `after_scheduler` (and through it the optimizer); `optimizer` = torch.optim.AdamW.state_dict() over
+    model.parameters().  The weights-only unpickler refuses it; with the explicit opt-in it loads, the scheduler's call count and
+    the Adam moments are taken over."""
+    import pytest
+    from collections import OrderedDict
+    from mmgl_amd.distributed import DataParallelEngine
+    from mmgl_amd.language_modelling.run_generation import load_checkpoint
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.01)
+    net(torch.randn(2, 8)).sum().backward()
+    opt.step()
+    after = torch.optim.lr_scheduler.StepLR(opt, step_size=7, gamma=0.5)
+    # what warmup_scheduler.GradualWarmupScheduler.state_dict() returns: its __dict__ minus `optimizer`
+    warm = dict(multiplier=1.0, total_epoch=3, after_scheduler=after, finished=True, base_lrs=[1e-3], last_epoch=5, _step_count=6)
+    path = str(tmp_path / "ref_ckpt.pth.tar")
+    torch.save({"epoch": 2, "best_acc1": 0.25, "state_dict": OrderedDict(("module." + k, v) for k, v in net.state_dict().items()),
+                "optimizer": opt.state_dict(), "scheduler": warm}, path)
+
+    net2 = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+    eng = DataParallelEngine(net2, lr=1e-3, fused=False)
+    sched = WarmupStepLR(1e-3, 3, 7, 0.5)
+    with pytest.raises(RuntimeError, match="MMGL_TRUST_CHECKPOINT"):
+        load_checkpoint(path, net2, eng, sched, "cpu")
+    ck = load_checkpoint(path, net2, eng, sched, "cpu", trust=True)
+    assert ck["epoch"] == 2 and sched.last_step == 5 and eng.step_count == 1
+    for (k, v), (_, w) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert torch.equal(v, w), k
+    ref_m = opt.state_dict()["state"]
+    names = [n for n, _ in net2.named_parameters()]
+    for n, p, o in zip(eng.names, eng.params, eng.offsets):
+        assert torch.equal(eng.exp_avg[o:o + p.numel()].view(p.shape), ref_m[names.index(n)]["exp_avg"]), n
+
+
 def test_schedule_and_bleu():
     s = WarmupStepLR(1e-3, 4, 3, 0.1)
     lrs = [s.step() for _ in range(11)]
