@@ -261,6 +261,15 @@ int mmgl_gemm_nt(const void* x, int ldx, const void* W, int ldw, const void* bia
                  void* y, int ldy, int M, int N, int K, int act, float out_scale, void* workspace, size_t workspace_bytes,
                  int dtype, void* stream);
 int mmgl_relu_bwd(const void* dy, const void* y, void* out, size_t n, int dtype, void* stream);
+/* Dynamic tile schedule of the persistent bf16 GEMM kernel behind mmgl_gemm_nt / _relu_bits / _masked / mmgl_linear_*.
+ * replaces: nothing in the reference -- it is what lets those GEMMs share the GPU with the gradient all-reduce that
+ *   DistributedDataParallel overlaps with the backward pass (language_modelling/run_generation.py:317-319, 485): with the default
+ *   static schedule (tile i * grid + workgroup) a workgroup whose CU is shared with the collective's kernel finishes its tiles
+ *   late and the whole GEMM waits for it (+38 % measured); with a counter, workgroups take tiles as they become free.
+ *   counter: DEVICE pointer to 16 uint32, all zero, owned by the caller and left all zero by every launch; NULL (the default)
+ *   = static schedule.  The setting belongs to the calling host thread (like mmgl_last_error) and applies to its later GEMM
+ *   launches; launches that may run concurrently on the device (different streams) must be given different counters. */
+int mmgl_gemm_set_tile_counter(void* counter);
 /* The ReLU mask of a frozen FFN as bits (replaces: keeping relu(fc1(x)) [M, ffn] for autograd's threshold_backward of
  * model/modelling_cross_attention.py:352-355, and re-reading it in fc2's dgrad).
  *   mmgl_gemm_nt_relu_bits: y = relu((x W^T + bias) * out_scale) as mmgl_gemm_nt with act = 1, plus bits_out: one bit per

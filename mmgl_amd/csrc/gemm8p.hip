@@ -39,6 +39,7 @@ typedef unsigned p8_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int P8_UNIT = 16384;      // bytes per staged unit
 constexpr int P8_LDS = 8 * P8_UNIT;
 constexpr int P8_LDS_TOTAL = P8_LDS + 16 * 1024;     // + two 1 KiB bias lines per wave (tile parity)
+constexpr int P8_LDS_ALLOC = P8_LDS_TOTAL + 64;      // + the dynamic schedule's mailbox
 
 struct P8Args {
     const bf16* X;
@@ -61,7 +62,27 @@ struct P8Args {
     int stag_mask;         // CU groups - 1 (power of two; group = CU index within its XCD & mask)
     long long* trace;      // timing experiments only (P8_TRACE builds): [8 waves][64] clock stamps of workgroup trace_wg
     int trace_wg;
+    unsigned* sched;       // dynamic tile schedule (mmgl_gemm_set_tile_counter): [0..7] per-XCD item counters, [8] finished workgroups;
+                           // all zero between launches.  NULL: static schedule (work item it * gridDim + wg)
 };
+
+// Work items of a launch in the order XCD j takes them (j = blockIdx & 7 when the grid is a multiple of 8, else one list): item k
+// of list j is virtual id (k / Gx) * G + j * Gx + k % Gx -- round by round the XCD's 8 x 4 group of tiles (grouped_tile), exactly
+// the static schedule's assignment.  The DYNAMIC schedule hands ALL items out through one atomic counter per list: a workgroup
+// whose CU is shared with (or was held back by) another kernel -- RCCL's all-reduce during the backward pass -- simply takes fewer
+// of them, or none, instead of finishing its statically assigned tiles late while 255 CUs wait (the round-2 measurement: any
+// co-resident kernel stretched a GEMM by 38 %; with only the later rounds dynamic the displaced workgroups' first tiles still ran
+// last: +11 %).  A list that runs dry is refilled from the next XCD's (a steal costs the L2 locality of that tile only).
+// Returns the virtual id, or -1 when every list is empty.
+__device__ __forceinline__ int p8_fetch_item(unsigned* sched, int xcd, int nlists, int G, int Gx, int nitems) {
+    for (int t = 0; t < nlists; ++t) {
+        const int j = xcd + t < nlists ? xcd + t : xcd + t - nlists;
+        const unsigned k = atomicAdd(&sched[j], 1u);
+        const long long v = (long long)(k / (unsigned)Gx) * G + j * Gx + (int)(k % (unsigned)Gx);
+        if (v < nitems) return (int)v;
+    }
+    return -1;
+}
 
 // ACT is a compile-time family: 0 = none, 1 = ReLU, 2 gelu (erf), 3 quick_gelu, 4 gelu (tanh)
 template <int ACT> __device__ __forceinline__ float p8_act(float v) {
@@ -154,9 +175,11 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     const int wg = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     // work item -> (tile origin, first K element, K tiles): with a K split the K range is cut into nsplit runs of whole
     // 128-wide steps (the first K/128 % nsplit runs one step longer)
-    auto tile_origin = [&](int it, int& m0, int& n0, int& k0, int& nki, int& sp) -> bool {
-        const int v = it * G + wg;
-        if (v >= a.total * a.nsplit) return false;
+    const bool dyn = a.sched != nullptr;
+    const int nlists = (G & 7) == 0 ? 8 : 1, Gx = G / nlists, xcd = nlists == 8 ? (int)(blockIdx.x & 7) : 0;
+    int* mailbox = (int*)(smem + P8_LDS_TOTAL);           // dynamic schedule: the item after next, by tile parity (written a whole tile ahead)
+    auto item_origin = [&](int v, int& m0, int& n0, int& k0, int& nki, int& sp) -> bool {
+        if (v < 0 || v >= a.total * a.nsplit) return false;
         int tm, tn;
         sp = v % a.nsplit;
         grouped_tile(a.tile0 + v / a.nsplit, a.tiles_m, a.tiles_n, tm, tn);
@@ -167,6 +190,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         nki = (base + (sp < rem ? 1 : 0)) * 2;
         return true;
     };
+    auto tile_origin = [&](int it, int& m0, int& n0, int& k0, int& nki, int& sp) -> bool { return item_origin(it * G + wg, m0, n0, k0, nki, sp); };
     // rows [row0, rows) of an operand with row stride ld: everything past the last row reads as zero.  (A K tile may run past
     // the end of a ROW when the caller pads K -- lm_head's dgrad contracts over V = 50272 -- and then reads the start of the next
     // row: finite values that meet the zero padding of the other operand.)
@@ -252,8 +276,19 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
 
     int m0 = 0, n0 = 0, m1 = 0, n1 = 0, k0 = 0, k1 = 0, nk1 = 0, sp0 = 0, sp1 = 0;
     int it = 0;
-    if (!tile_origin(0, m0, n0, k0, nk, sp0)) return;
-    bool have_next = tile_origin(1, m1, n1, k1, nk1, sp1);
+    int vcur = wg, vnext = G + wg;                        // virtual ids of the current / next work item (static schedule: it * G + wg)
+    if (dyn) {                                            // the first item: one lane asks, everybody waits (~1 us, once per launch)
+        if (tid == 0) mailbox[2] = p8_fetch_item(a.sched, xcd, nlists, G, Gx, a.total * a.nsplit);
+        __syncthreads();
+        vcur = mailbox[2];
+        if (vcur < 0) {                                   // nothing left for this workgroup (it started late: its CU was busy)
+            if (tid == 0 && atomicAdd(&a.sched[8], 1u) == (unsigned)G - 1u)
+                for (int i = 0; i < 9; ++i) atomicExch(&a.sched[i], 0u);
+            return;
+        }
+    }
+    if (!item_origin(vcur, m0, n0, k0, nk, sp0)) return;  // (static: grid <= items, every workgroup has its round-0 item)
+    bool have_next = dyn ? false : tile_origin(1, m1, n1, k1, nk1, sp1);    // dynamic: known after the prologue's barrier
     __amdgpu_buffer_rsrc_t dXc = mk_desc(a.X, m0, a.M, a.ldx, k0, true), dWc = mk_desc(a.W, n0, a.N, a.ldw, k0, true);
     __amdgpu_buffer_rsrc_t dXn = mk_desc(a.X, m1, a.M, a.ldx, k1, have_next), dWn = mk_desc(a.W, n1, a.N, a.ldw, k1, have_next);
 
@@ -291,7 +326,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
             const int ncol_l = wc * 64 + 8 * (ln >> 4);
             const unsigned base = (unsigned)(((wr * 128 + (ln & 15)) * 256 + ncol_l) * 4);
             const unsigned rstep = (unsigned)(16 * 256 * 4);
-            const int vitem = par * G + wg;                                  // = (tile - tile0) * nsplit + split
+            const int vitem = vcur;                                          // = (tile - tile0) * nsplit + split
             const __amdgpu_buffer_rsrc_t dP = __builtin_amdgcn_make_buffer_rsrc((void*)(a.part + ((size_t)vitem << 16)), 0, 256 * 256 * 4, 0x00020000);
 #pragma unroll
             for (int T0 = 0; T0 < 4; T0 += 2)
@@ -319,7 +354,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         if constexpr (ZR) {
             const __amdgpu_buffer_rsrc_t dZ = y_desc(a.zmask ? a.zmask : a.resid, m0);
             if (a.bits_in) {                         // 16 bytes per lane instead of 16 x 16: the ReLU mask as bits (see bits_out)
-                mbits = *(const p8_u32x4*)(a.bits_in + ((size_t)((a.tile0 + par * G + wg) * 8 + wave) * 64 + ln) * 4);
+                mbits = *(const p8_u32x4*)(a.bits_in + ((size_t)((a.tile0 + vcur) * 8 + wave) * 64 + ln) * 4);
             } else if (a.zmask) {                           // read once, never again: non-temporal (-2.5 % on the fc2 dgrad); a residual tile is
 #pragma unroll                                       // the stream the next kernels read too: default policy (nt: +1.5 %)
                 for (int q = 0; q < 4; ++q)
@@ -432,7 +467,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
             else if (a.zmask) rows(std::integral_constant<int, 1>());
             else rows(std::integral_constant<int, 2>());
             if constexpr (ACT == 1 && !ZR) {
-                if (a.bits_out) a.bits_out[((size_t)((a.tile0 + par * G + wg) * 8 + wave) * 64 + ln) * 4 + q] = qbits;
+                if (a.bits_out) a.bits_out[((size_t)((a.tile0 + vcur) * 8 + wave) * 64 + ln) * 4 + q] = qbits;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { acc[T0][J0 + j] = vzero<f32x4>(); acc[T0 + 1][J0 + j] = vzero<f32x4>(); }
@@ -466,6 +501,11 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     // two W fragment sets that swap roles every K tile: even K tiles keep Wa in fwA and Wb in fwB, odd ones Wa in fwB, Wb in fwA
     bf16x8 fx[2][4], fwA[2][2], fwB[2][2];
     fetch_bias(n0, 0);                   // the lane's 16 bias values of the first tile
+    if (dyn && tid == 0) {               // the next two work items of this workgroup (one lane asks, the mailbox tells the other waves)
+        mailbox[0] = p8_fetch_item(a.sched, xcd, nlists, G, Gx, a.total * a.nsplit);
+        mailbox[1] = p8_fetch_item(a.sched, xcd, nlists, G, Gx, a.total * a.nsplit);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 #if P8_RELAX
     P8_VMCNT(0);                         // the whole prologue has landed: the relaxed counts of a tile's first phases assume that
 #else                                    // everything issued before the tile is complete, or older than the epilogue's stores
@@ -475,6 +515,12 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     rdW(fwA, 7);
     P8_LGKM0();
     if (wr) P8_BARRIER();                // waves 4-7 run half a phase behind waves 0-3
+    if (dyn) {
+        vnext = mailbox[0];
+        have_next = item_origin(vnext, m1, n1, k1, nk1, sp1);
+        dXn = mk_desc(a.X, m1, a.M, a.ldx, k1, have_next);
+        dWn = mk_desc(a.W, n1, a.N, a.ldw, k1, have_next);
+    }
 
     // One phase.  READ: this phase's fragments.  (TY, SLOT, DK): the unit staged now = the one read 6 phases from now, of
     // K tile kt + DK (past the end of this output tile: K tile kt + DK - nk of the next one).  vmcnt(10): the 5 younger units
@@ -587,9 +633,15 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
 #if P8_REALIGN
             if (!wr) P8_BARRIER();
 #endif
+            // dynamic schedule: one lane asks for the item after the next one now -- the answer comes back under the epilogue -- and
+            // leaves it in the mailbox slot of this tile's parity, which every wave reads at the NEXT tile switch (a whole tile and
+            // dozens of barriers from now; the other slot is the one being read at this switch)
+            int fetched = -1;
+            if (dyn && tid == 0 && have_next) fetched = p8_fetch_item(a.sched, xcd, nlists, G, Gx, a.total * a.nsplit);
 #if !(P8_ABLATE & 1)
             epilogue();
 #endif
+            if (dyn && tid == 0) mailbox[it & 1] = fetched;
             P8_STAMP(it);
 #if P8_REALIGN
             if (!have_next) { if (wr) P8_BARRIER(); break; }
@@ -606,7 +658,9 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         sp0 = sp1;
         dXc = dXn;
         dWc = dWn;
-        have_next = tile_origin(it + 1, m1, n1, k1, nk1, sp1);
+        vcur = vnext;
+        vnext = dyn ? mailbox[it & 1] : (it + 1) * G + wg;       // the slot written at the PREVIOUS switch (or by the prologue)
+        have_next = item_origin(vnext, m1, n1, k1, nk1, sp1);
         dXn = mk_desc(a.X, m1, a.M, a.ldx, k1, have_next);
         dWn = mk_desc(a.W, n1, a.N, a.ldw, k1, have_next);
         fetch_bias(n0, it);              // the next tile's bias values: consumed by its epilogue a whole tile from now
@@ -616,6 +670,13 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     }
     P8_VMCNT(0);                         // no LDS-DMA may outlive the workgroup
     if (!wr) P8_BARRIER();               // balance the stagger barrier
+    if (dyn && tid == 0) {
+        // every workgroup has stopped asking by now; the last one to leave puts the counters back to zero for the next launch
+        if (atomicAdd(&a.sched[8], 1u) == (unsigned)G - 1u) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) atomicExch(&a.sched[i], 0u);
+        }
+    }
 }
 
 // fold the K splits of ACT = 5 work items and apply the epilogue:  Y = act((sum_s part[s] + bias) * scale) (zmask, + resid)
@@ -728,6 +789,9 @@ size_t gemm8p_split_bytes(int M, int N, int K) {
     return sp ? (size_t)(cdiv(M, 256) * cdiv(N, 256) - d) * sp * (256 * 256 * sizeof(float)) : 0;
 }
 
+// the calling thread's tile counters (mmgl_gemm_set_tile_counter); NULL = static tile schedule
+static thread_local unsigned* g_tile_counter = nullptr;
+
 int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, const bf16* resid,
                   const bf16* zmask, int M, int N, int K, int act, float scale, hipStream_t st, float* part, size_t part_bytes,
                   unsigned* bits_out, const unsigned* bits_in) {
@@ -755,7 +819,7 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
                              (const void*)gemm8p_kernel<1, true>,  (const void*)gemm8p_kernel<2, false>, (const void*)gemm8p_kernel<3, false>,
                              (const void*)gemm8p_kernel<3, true>,  (const void*)gemm8p_kernel<4, true>,  (const void*)gemm8p_kernel<5, false>};
         for (const void* kf : ks) {
-            hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_TOTAL);
+            hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_ALLOC);
             if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
     }
@@ -770,6 +834,7 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
     a.stagger = 0;
     a.stag_mask = 0;
     a.tile0 = 0;
+    a.sched = g_tile_counter;
     if (direct > 0) {
         a.total = direct;
         const int grid = direct < n_cu ? direct : n_cu;
@@ -785,7 +850,7 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
         if (const char* e = getenv("MMGL_P8_TRACE_WG")) a.trace_wg = atoi(e);
 #endif
         const bool zr = resid || zmask || bits_in;
-#define P8_LAUNCH(A, Z) hipLaunchKernelGGL((gemm8p_kernel<A, Z>), dim3(grid), dim3(512), P8_LDS_TOTAL, st, a)
+#define P8_LAUNCH(A, Z) hipLaunchKernelGGL((gemm8p_kernel<A, Z>), dim3(grid), dim3(512), P8_LDS_ALLOC, st, a)
         switch (act) {
             case 0: if (zr) P8_LAUNCH(0, true); else P8_LAUNCH(0, false); break;
             case 1: if (zr) P8_LAUNCH(1, true); else P8_LAUNCH(1, false); break;
@@ -808,7 +873,7 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
         a.stag_mask = 0;
         a.trace = nullptr;
         const int items = rest * nsplit, g = items < n_cu ? items : n_cu;
-        hipLaunchKernelGGL((gemm8p_kernel<5, false>), dim3(g), dim3(512), P8_LDS_TOTAL, st, a);
+        hipLaunchKernelGGL((gemm8p_kernel<5, false>), dim3(g), dim3(512), P8_LDS_ALLOC, st, a);
         MMGL_CHECK_LAUNCH("gemm8p (K split)");
         int blocks = rest * 32;                                  // 8192 vectors per tile, 256 per block and trip
         if (blocks > 2048) blocks = 2048;
@@ -816,5 +881,10 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
                            direct, rest, a.tiles_m, a.tiles_n);
         MMGL_CHECK_LAUNCH("gemm8p split-K finish");
     }
+    return MMGL_OK;
+}
+
+extern "C" int mmgl_gemm_set_tile_counter(void* counter) {
+    g_tile_counter = (unsigned*)counter;
     return MMGL_OK;
 }

@@ -785,6 +785,26 @@ def _transposed(weight, pad_to=1):
     return hit[2]
 
 
+_tile_counters = {}
+
+
+def gemm_dynamic_schedule(enable=True, device=None):
+    """Switch this process's persistent-GEMM launches between the static tile schedule (default) and the dynamic one
+    (mmgl_gemm_set_tile_counter): workgroups take tiles from per-XCD counters as they become free.  The data-parallel engine
+    turns it on when it runs with more than one rank: the bucket all-reduces of the backward pass share the CUs with these GEMMs,
+    and a statically scheduled GEMM waits for its displaced workgroups (reference DDP overlap: run_generation.py:317-319, 485).
+    One counter block per device; every launch leaves it zeroed, GEMMs of one process run on one stream."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if not enable:
+        lib().mmgl_gemm_set_tile_counter(None)
+        return None
+    c = _tile_counters.get(device)
+    if c is None:
+        c = _tile_counters[device] = torch.zeros(16, dtype=torch.int32, device=device)
+    lib().mmgl_gemm_set_tile_counter(ptr(c))
+    return c
+
+
 def gemm_nt(x2, w, bias=None, residual=None, zmask=None, act=0, out_scale=1.0, K=None, out=None):
     """Raw mmgl_gemm_nt call: act((x2[:, :K] @ w[:, :K]^T + bias) * out_scale) [zeroed where zmask <= 0] [+ residual].
     x2 [M, >=K] and w [N, >=K] are row-major with unit column stride (their row strides are passed as ldx / ldw: K may exceed

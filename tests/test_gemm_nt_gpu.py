@@ -210,3 +210,45 @@ def test_training_step_does_not_build_logits():
     lm.train()
     o3 = lm(**kw, return_logits=True)
     assert o3.logits.shape == (2, 24, 128)
+
+
+@pytest.mark.parametrize("M,N,K,act,bias,resid,zmask,scale", [CASES[i] for i in (0, 1, 3, 4, 6, 8, 11, 12)])
+def test_dynamic_tile_schedule_is_bitwise_the_static_one(M, N, K, act, bias, resid, zmask, scale):
+    """mmgl_gemm_set_tile_counter: tiles handed out through per-XCD atomic counters instead of `tile = i * grid + workgroup` --
+    several rounds of tiles, ragged edges, K-split items, the hybrid plan.  Same tiles, same arithmetic per tile => bit-identical
+    output; every launch leaves the counters at zero (the next launch depends on it)."""
+    from mmgl_amd import ops
+    x, W, b, r, z = _mk(M, N, K, seed=M + N + K, bias=bias, resid=resid, zmask=zmask)
+    y0 = ops.gemm_nt(x, W, b, r, z, act=act, out_scale=scale)
+    ctr = ops.gemm_dynamic_schedule(True)
+    try:
+        y1 = ops.gemm_nt(x, W, b, r, z, act=act, out_scale=scale)
+        y2 = ops.gemm_nt(x, W, b, r, z, act=act, out_scale=scale)
+        torch.cuda.synchronize()
+        assert int(ctr.abs().sum()) == 0, ctr.tolist()
+    finally:
+        ops.gemm_dynamic_schedule(False)
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)
+
+
+def test_dynamic_tile_schedule_ffn_relu_bits():
+    """The frozen FFN pair under the dynamic schedule: fc1 writes its ReLU mask as bits indexed by the tile's virtual id, fc2's dgrad
+    reads them back -- whichever workgroup happened to take the tile."""
+    from mmgl_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(10240, 2048, device="cuda").bfloat16().requires_grad_()
+    w1 = (torch.randn(8192, 2048, device="cuda") * 0.02).bfloat16()
+    b1 = torch.randn(8192, device="cuda").bfloat16()
+    w2 = (torch.randn(2048, 8192, device="cuda") * 0.02).bfloat16()
+
+    def run():
+        y = ops.frozen_linear(ops.frozen_linear(x, w1, b1, relu=True, bwd_premasked=True), w2, None, mask_dx=True)
+        (g,) = torch.autograd.grad(y.float().square().mean(), x)
+        return y.detach(), g
+    y0, g0 = run()
+    ops.gemm_dynamic_schedule(True)
+    try:
+        y1, g1 = run()
+    finally:
+        ops.gemm_dynamic_schedule(False)
+    assert torch.equal(y0, y1) and torch.equal(g0, g1)

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from mmgl_amd import ops  # noqa: E402
 
-occ = ctypes.CDLL(os.path.join(ROOT, "build_probe", "liboccupier.so"))
+so = os.path.join(ROOT, "variants", "liboccupier.so")      # hipcc -O2 --offload-arch=gfx950 -shared -fPIC -o variants/liboccupier.so tools/probes/occupier.hip
+occ = ctypes.CDLL(so if os.path.exists(so) else os.path.join(ROOT, "build_probe", "liboccupier.so"))
 occ.occupier_spin.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
 
 
@@ -24,7 +25,9 @@ def main():
     for _ in range(5):
         ops.gemm_nt(x, w, out=y)
     torch.cuda.synchronize()
-    for wgs in (0, 8, 16, 32, 64):
+    for dynamic in (False, True):
+      ops.gemm_dynamic_schedule(dynamic)
+      for wgs in (0, 8, 16, 32, 64):
         best = 1e9
         for _ in range(3):
             torch.cuda.synchronize()
@@ -37,7 +40,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / 8 * 1e3)
-        print(f"occupier workgroups {wgs:3d}: {M}x{N}x{K} {best:7.1f} us per GEMM", flush=True)
+        print(f"{'dynamic' if dynamic else 'static ':7s} schedule, occupier workgroups {wgs:3d}: {M}x{N}x{K} {best:7.1f} us per GEMM", flush=True)
+    ops.gemm_dynamic_schedule(False)
 
 
 if __name__ == "__main__":
