@@ -51,11 +51,11 @@ int mmgl_version(void);
  *   lse       [B,H,T] fp32 log-sum-exp of the masked scores (saved for backward)
  * A sample with no valid key yields the uniform distribution over its S keys (the reference's
  * finfo.min clamp, :226-228), never NaN.  D in {16,32,64,128}; S <= 256.
- * p_drop must be 0 (OPT's attention_dropout is 0.0; :256 is then the identity).
+ * No attention dropout (:256): OPT's attention_dropout is 0.0, where it is the identity; the host mirror raises ValueError for
+ * a config that asks for it instead of carrying inert p / seed / offset arguments here.
  */
 int mmgl_xattn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid,
-                   void* out, float* lse, int B, int H, int T, int S, int D,
-                   float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream);
+                   void* out, float* lse, int B, int H, int T, int S, int D, int dtype, void* stream);
 
 /* Backward of the above.  dq [B,T,H*D], dk/dv [B,S,H*D].  `workspace` must hold
  * mmgl_xattn_bwd_workspace(...) bytes (fp32 row-dots + per-chunk dK/dV partials, reduced in a

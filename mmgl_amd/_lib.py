@@ -23,7 +23,7 @@ P, I, F, Z, U, L = c_void_p, c_int, c_float, c_size_t, c_u64, c_i64
 SIGNATURES = {
     "mmgl_last_error": (ctypes.c_char_p, []),
     "mmgl_version": (I, []),
-    "mmgl_xattn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, U, U, I, P]),
+    "mmgl_xattn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "mmgl_xattn_bwd_workspace": (Z, [I, I, I, I, I]),
     "mmgl_xattn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, P]),
     "mmgl_selfattn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P]),

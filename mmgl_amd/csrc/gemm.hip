@@ -309,10 +309,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const bf16* __restri
 // tiles to fill the chip twice (below that the 128x128 kernel's finer tiling wins)
 inline bool big_tile_shape(int M, int N, int K) { return K % 64 == 0 && (size_t)cdiv(M, 256) * cdiv(N, 256) >= 512; }
 
-inline int tune_gemm_8p() {
-    static const int v = [] { const char* e = getenv("MMGL_GEMM_8P"); return e ? atoi(e) : 1; }();
-    return v;
-}
+// the persistent ping-pong kernel (gemm8p.hip) takes every bf16 shape it supports; the 256x256 / 128x128 kernels of this file are
+// what the remaining shapes run on (K not a multiple of 128, accumulating outputs, fp32, few tiles)
+inline constexpr int tune_gemm_8p() { return 1; }
 // few-tile shapes (>= 24 tiles: below that even 8 splits leave most of the chip idle and the 128x128 kernel's 4x finer tiles win)
 inline bool gemm8p_use_splits(int M, int N, int K) {
     static const int on = [] { const char* e = getenv("MMGL_GEMM_8P_SPLITK"); return e ? atoi(e) : 1; }();

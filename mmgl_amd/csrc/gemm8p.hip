@@ -112,9 +112,6 @@ __device__ __forceinline__ int p8_lane() {
     return l;
 }
 
-#ifndef P8_SPREAD
-#define P8_SPREAD 0                  // 1: epilogue of tile i quadrant by quadrant inside the first four phases of tile i+1 (measured 7 % slower)
-#endif
 #ifndef P8_RELAX
 #define P8_RELAX 0                   // 1: relaxed vmcnt in a tile's first five phases (peeled first K-tile pair); measured neutral, kept for experiments
 #endif
@@ -558,49 +555,9 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     // of them, so the count that keeps "5 younger units in flight" grows by 17: with vmcnt(10) the first phase of every tile
     // would wait for the stores to be acknowledged (a 128 KiB burst per CU: 3-10k clocks) instead of running under them.
 #define P8_PHASE_T(READ, TY, SLOT, DK, FX, FW, J0, T0) P8_PHASE_M(READ, TY, SLOT, DK, FX, FW, J0, T0, P8_MM, 27)
-    // Spread epilogue (kernels without zmask / residual loads).  A quadrant of accumulators is not touched again until the
-    // phase of the NEXT tile that restarts it, so tile i's epilogue runs quadrant by quadrant at the head of the first four
-    // phases of tile i+1 -- in this wave group's memory cluster, beside the partner group's MFMA cluster -- instead of as one
-    // block between the tiles during which the matrix pipes idle and 128 KiB of stores hit the CU's store path at once.  Four
-    // stores per wave and phase join the in-order VMEM queue ahead of that phase's LDS-DMA, so the counted waits of the tile's
-    // first eight phases grow by the stores still younger than the unit each one needs (14, 18, 22, 26, 26, 22, 18, 14 instead of
-    // 10).  The first tile of a workgroup has nothing to store (plain loop: the relaxed counts would not cover its own units) and
-    // the last one ends with the block epilogue.
-    // MEASURED: correct, and 7 % SLOWER over the step's shapes (6.67 -> 7.14 ms for the nine of tools/probes/gemm_variants.py): a
-    // wave cannot issue its next store while the CU's store path is backed up (128 KiB take ~8k clocks to leave the CU, four
-    // phases are 2.2k), so the stall moves into the memory cluster, which the partner group waits for at every barrier.  The
-    // block epilogue stalls only once.  Left here, off, as the record of the experiment.
-    constexpr bool SPREAD = P8_SPREAD && !ZR && ACT != 5;
-#define P8_PHASE_S(Q, WAITN, READ, TY, SLOT, DK, FX, FW, J0, T0)                                  \
-    do {                                                                                         \
-        epilogue_q(pm0, pn0, it - 1, (Q), (Q) + 1);                                              \
-        P8_PHASE_M(READ, TY, SLOT, DK, FX, FW, J0, T0, P8_MM, WAITN);                            \
-    } while (0)
-    int pm0 = 0, pn0 = 0;
     for (;;) {
         P8_STAMP(it);
-        int kt_begin = 0;
-        if (SPREAD && it > 0) {
-            const int kt = 0;
-            P8_PHASE_S(0, 14, rdX(fx, 0), 2, 6, 1, fx, fwA, 0, 0);
-            P8_STAMP(it);
-            P8_PHASE_S(1, 18, rdW(fwB, 1), 3, 7, 2, fx, fwB, 0, 2);
-            P8_STAMP(it);
-            P8_PHASE_S(2, 22, rdX(fx, 2), 0, 0, 2, fx, fwB, 4, 2);
-            P8_STAMP(it);
-            P8_PHASE_S(3, 26, rdW(fwB, 3), 1, 1, 2, fx, fwA, 4, 0);
-            P8_STAMP(it);
-            P8_PHASE_M(rdX(fx, 4), 2, 2, 2, fx, fwB, 0, 0, P8_MM, 26);
-            P8_STAMP(it);
-            P8_PHASE_M(rdW(fwA, 5), 3, 3, 3, fx, fwA, 0, 2, P8_MM, 22);
-            P8_STAMP(it);
-            P8_PHASE_M(rdX(fx, 6), 0, 4, 3, fx, fwA, 4, 2, P8_MM, 18);
-            P8_STAMP(it);
-            P8_PHASE_M(rdW(fwA, 7), 1, 5, 3, fx, fwB, 4, 0, P8_MM, 14);
-            P8_STAMP(it);
-            kt_begin = 2;
-        }
-        for (int kt = kt_begin; kt < nk; kt += 2) {
+        for (int kt = 0; kt < nk; kt += 2) {
             P8_PHASE(rdX(fx, 0), 2, 6, 1, fx, fwA, 0, 0);
             if (kt < 4) P8_STAMP(it);
             P8_PHASE(rdW(fwB, 1), 3, 7, 2, fx, fwB, 0, 2);
@@ -619,12 +576,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
             if (kt < 4) P8_STAMP(it);
         }
         P8_STAMP(it);
-        if (SPREAD) {
-            if (!have_next) {                                // last tile of this workgroup: block epilogue
-                epilogue();
-                break;
-            }
-        } else {
+        {
             // The two wave groups reach this point half a phase apart, and whichever runs its epilogue holds the other at its
             // next barrier: left alone, the two epilogues (and tile switches) run one after the other (~13k clocks per tile in
             // the clock stamps).  One extra barrier each re-aligns them: waves 0-3 take theirs before the epilogue (it pairs with
@@ -649,8 +601,6 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
             if (!have_next) break;
 #endif
         }
-        pm0 = m0;
-        pn0 = n0;
         ++it;
         m0 = m1;
         n0 = n1;
@@ -665,7 +615,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         dWn = mk_desc(a.W, n1, a.N, a.ldw, k1, have_next);
         fetch_bias(n0, it);              // the next tile's bias values: consumed by its epilogue a whole tile from now
 #if P8_REALIGN
-        if (!SPREAD && wr) P8_BARRIER();
+        if (wr) P8_BARRIER();
 #endif
     }
     P8_VMCNT(0);                         // no LDS-DMA may outlive the workgroup

@@ -7,9 +7,6 @@
 // between lanes, V^T / K^T fragments via ds_read_b64_tr_b16), plus the online-softmax loop over 64-key tiles that a
 // 640..2176-key sequence needs.  Backward = flash backward: delta = rowsum(dO*O) pre-pass, a dQ kernel (loop over key
 // tiles per query tile) and a dK/dV kernel (loop over query tiles per key tile, no atomics, no global partials).
-#ifdef SA_QT_FORCE                  // timing experiments: 16-row (1) / 32-row (2) query tiles per wave in this file only
-#define MMGL_XATTN_QT_FORCE SA_QT_FORCE
-#endif
 #include "attn_common.h"
 #include "selfattn32.h"
 #include <type_traits>
@@ -17,9 +14,6 @@
 namespace {
 
 constexpr int KT = 64;            // keys per tile (NSB = 4)
-#ifndef SA_ABLATE
-#define SA_ABLATE 0               // timing experiments only (1: K/V tiles fetched once, 2: no per-tile barrier); never set in a shipped build
-#endif
 
 template <typename T, int D> struct SC : XC<T, D, 4, 1> {};
 
@@ -104,9 +98,6 @@ template <typename T, typename C, bool K_ROWMAJOR, bool V_ROWMAJOR> struct TileS
     // branch-free form: rows past the end of the sequence / padding channels fall outside the descriptor and read as 0
     __device__ __forceinline__ void loadb(__amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv, uint32_t row_bytes,
                                           const uint8_t* valid_row, int s0, int T_) {
-#if SA_ABLATE & 1                           // timing experiment: only the first tile is fetched (results are wrong)
-        if (s0 > 0) return;
-#endif
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int id = threadIdx.x + i * 256, s = id / C::CPR, c = id % C::CPR;
@@ -242,9 +233,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const T* __restrict__
             }
         }
         if (j + 1 < nkt) stg.store(Kimg((j + 1) & 1), Vimg((j + 1) & 1), Vld((j + 1) & 1));
-#if !(SA_ABLATE & 2)
         __syncthreads();
-#endif
     }
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
@@ -355,9 +344,7 @@ __global__ __launch_bounds__(256) void encattn_fwd_kernel(const T* __restrict__ 
                 for (int qt = 0; qt < C::QT; ++qt) mma16(oacc[qt][db], vt, pf[qt][ks]);
             }
         if (j + 1 < nkt) stg.store(Kimg((j + 1) & 1), Vimg((j + 1) & 1), Vld((j + 1) & 1));
-#if !(SA_ABLATE & 2)
         __syncthreads();
-#endif
     }
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
@@ -533,9 +520,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const T* __restric
             }
         }
         if (j + 1 < nkt) stg.store(Kimg((j + 1) & 1), Vimg((j + 1) & 1), Vld((j + 1) & 1));
-#if !(SA_ABLATE & 2)
         __syncthreads();
-#endif
     }
 #pragma unroll
     for (int qt = 0; qt < C::QT; ++qt) {
@@ -750,25 +735,9 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
 // dV += P^T dO, dK += dS^T Q.  Branch-free body: bounds by buffer descriptors, masks by selects feeding exp2(-inf) = 0.
 // No barrier, no cross-wave reduction: every dK / dV element is produced by one wave.
 // NSBW = 16-key blocks per wave: 4 (64 keys) up to D = 64, 2 (32 keys) at D = 128 (the dK / dV accumulators are NSBW * D / 4 registers each)
-// DB: two register sets for the Q / dO rows (the next tile in flight during this one: what a lone wave per SIMD needs); false:
-// one set, re-requested at the end of the step -- fits two waves per SIMD at 32 keys per wave, which then hide each other's latency
-#ifndef SA_DKV_AGPR
-#define SA_DKV_AGPR 0
-#endif
-// Experiment, off: dK / dV accumulators in AGPRs.  The file is built with MFMA results in plain VGPRs (the softmax arithmetic works
-// on every S / dP accumulator), which leaves this kernel's 128 dK / dV accumulator registers -- touched by nothing but MFMAs until
-// the end -- in VGPRs too and pushes Q / dO prefetch data out into AGPRs: 209 of the 809 instructions of a 64-row step are
-// v_accvgpr_read / write / mov copies.  An inline-asm MFMA with a "+a" accumulator pins them where they belong: 24 copies, 619
-// instructions -- for 920 -> 905 us per backward (B = 64) and a FAILING parity test: the hazard recognizer does not see inline-asm
-// MFMAs.  With one wave per SIMD the step is bound by its dependency chain (tile write -> transpose reads -> S / dP -> exp ->
-// dV / dK), not by issue slots (query tiles fetched only once, -DSA_ABLATE=4: 920 -> 870 us, so memory latency is not it either).
-__device__ __forceinline__ void mma16_agpr(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-#endif
-}
-
-template <int D, int NSBW, bool DB = true>
+// Two register sets for the Q / dO rows: the next tile is in flight during this one (what a lone wave per SIMD needs).  (A
+// 32-keys-per-wave, one-register-set form that fits two waves per SIMD was 15-38 % slower: every wave re-reads the whole Q / dO tile.)
+template <int D, int NSBW>
 __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ q,
                                                                 const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
@@ -802,7 +771,6 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(delta + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
 
-    [[maybe_unused]] const int tstart0 = max(s0 - P, 0) & ~31;
     v8 kf[NSBW][C::NDC], vf[NSBW][C::NDC];
     float kbias[NSBW];                                // 0 for a real, valid key of this lane's column; -inf otherwise
     // One wave per SIMD and nothing else to run: every exposed memory round trip of the prologue is idle time.  The key-valid bytes
@@ -826,9 +794,6 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
         for (int sbl = 0; sbl < NSBW; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
 
     auto request = [&](int tbase, v8 (&qn)[2][C::NDC], v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
-#if SA_ABLATE & 4                           // timing experiment: the query tiles are fetched once (results are wrong)
-        if (tbase > tstart0 + 32) return;
-#endif
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
 #pragma unroll
@@ -853,7 +818,7 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
     auto step = [&](auto diag_tag, int t0, v8 (&qa)[2][C::NDC], v8 (&ga)[2][C::NDC], float (&la)[2][4], float (&da)[2][4],
                     v8 (&qn)[2][C::NDC], v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
         constexpr bool DIAG = decltype(diag_tag)::value;
-        if constexpr (DB) request(t0 + 32, qn, gn, ln, dn);
+        request(t0 + 32, qn, gn, ln, dn);
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
@@ -910,16 +875,10 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
             const v8 pB = pack8<T>(pr[0], pr[1]), dsB = pack8<T>(dsr[0], dsr[1]);
 #pragma unroll
             for (int db = 0; db < C::NDB; ++db) {
-#if SA_DKV_AGPR
-                mma16_agpr(dva[db][sbl], gT[db], pB);
-                mma16_agpr(dka[db][sbl], qT[db], dsB);
-#else
                 mma16(dva[db][sbl], gT[db], pB);
                 mma16(dka[db][sbl], qT[db], dsB);
-#endif
             }
         }
-        if constexpr (!DB) request(t0 + 32, qn, gn, ln, dn);         // qn aliases qa: its last reader has been issued
     };
 
     typedef std::integral_constant<bool, true> on_diag;
@@ -932,16 +891,7 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
 #pragma unroll
         for (int sbl = 0; sbl < NSBW; ++sbl) kbias[sbl] = (s0 + sbl * 16 + x < Tk && kvalid[sbl] != 0) ? 0.f : -INFINITY;
     };
-    if constexpr (!DB) {
-        v8 qA[2][C::NDC], gA[2][C::NDC];
-        float lA[2][4], dA[2][4];
-        request(tstart, qA, gA, lA, dA);
-        finish_kbias();
-        for (int t0 = tstart; t0 < T_; t0 += 32) {
-            if (t0 < tdiag) step(on_diag(), t0, qA, gA, lA, dA, qA, gA, lA, dA);
-            else step(off_diag(), t0, qA, gA, lA, dA, qA, gA, lA, dA);
-        }
-    } else {
+    {
         v8 qA[2][C::NDC], gA[2][C::NDC], qB[2][C::NDC], gB[2][C::NDC];
         float lA[2][4], dA[2][4], lB[2][4], dB[2][4];
         request(tstart, qA, gA, lA, dA);
@@ -956,9 +906,6 @@ __global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __re
             if (t0 + 32 < T_) step(off_diag(), t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
         }
     }
-#if SA_DKV_AGPR
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last inline-asm MFMAs' results: the hazard recognizer does not see them
-#endif
 #pragma unroll
     for (int sbl = 0; sbl < NSBW; ++sbl) {
         const int s = s0 + sbl * 16 + x;
@@ -1035,22 +982,6 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
         static const int use64 = [] { const char* e = getenv("MMGL_SELFATTN_DKV64"); return e ? atoi(e) : 1; }();
         if constexpr (sizeof(T) == 2) {
             if (use64) {
-                static const int occ2 = [] { const char* e = getenv("MMGL_SELFATTN_DKV_OCC2"); return e ? atoi(e) : 0; }();
-                if (D <= 64 && occ2) {                       // 32 keys per wave, one register set: two waves per SIMD
-                    typedef XC<bf16, D, 2> C2;
-                    const int nkb32 = cdiv(T_ + P, 32);
-                    const size_t lds32 = sizeof(bf16) * 2 * 32 * (C2::DPAD + 16);
-                    if (occ2 == 2)                           // ... with the two-tile register pipeline as well
-                        hipLaunchKernelGGL((selfattn_bwd_dkv64_kernel<D, 2, true>), dim3(B * H * nkb32), dim3(64), lds32, st, (const bf16*)dout,
-                                           (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, (bf16*)dk, (bf16*)dv, B, H, T_,
-                                           nkb32, ldq, ldgk, P, ldk);
-                    else
-                        hipLaunchKernelGGL((selfattn_bwd_dkv64_kernel<D, 2, false>), dim3(B * H * nkb32), dim3(64), lds32, st, (const bf16*)dout,
-                                           (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, (bf16*)dk, (bf16*)dv, B, H, T_,
-                                           nkb32, ldq, ldgk, P, ldk);
-                    MMGL_CHECK_LAUNCH("selfattn_bwd_dkv32");
-                    return MMGL_OK;
-                }
                 constexpr int NSBW = D <= 64 ? 4 : 2;
                 typedef XC<bf16, D, NSBW> C4;
                 const int nkb64 = cdiv(T_ + P, 16 * NSBW);

@@ -1164,13 +1164,10 @@ int check_shape(const char* who, int B, int H, int T, int S, int D, int dtype) {
 }  // namespace
 
 extern "C" int mmgl_xattn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid, void* out,
-                              float* lse, int B, int H, int T, int S, int D, float p_drop, uint64_t seed,
-                              uint64_t offset, int dtype, void* stream) {
-    (void)seed; (void)offset;
+                              float* lse, int B, int H, int T, int S, int D, int dtype, void* stream) {
     int rc = check_shape("mmgl_xattn_fwd", B, H, T, S, D, dtype);
     if (rc) return rc;
     MMGL_CHECK_ARG(q && k && v && key_valid && out && lse, "mmgl_xattn_fwd: null pointer");
-    if (p_drop != 0.f) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "mmgl_xattn_fwd: attention dropout %g != 0 is not implemented", p_drop);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MMGL_BF16) DISPATCH_D(launch_fwd, bf16, q, k, v, key_valid, out, lse, B, H, T, S, st);
     DISPATCH_D(launch_fwd, float, q, k, v, key_valid, out, lse, B, H, T, S, st);

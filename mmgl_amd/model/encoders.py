@@ -14,9 +14,15 @@ parameters / state_dict keys; only their forward is replaced, for CUDA tensors, 
   * the last layer only produces what is consumed: keys/values for all tokens, but attention output, output projection,
     FFN and norms for the first (CLS) row of every sequence only.
 
-Forward only, no autograd (the encoders are frozen, reference :922-934).  Architectures this path does not cover
-(`supports()` is False: relative position embeddings, exotic activations, CLIP's text tower) keep their HF forward; inputs
-it cannot take (CPU tensors, a sequence whose first token is masked) raise.
+CLIP's TEXT tower (reference :918-921 accepts a `CLIPTextModel` as text_model) is a causal pre-LN encoder whose pooled
+output is the hidden state of the EOS token: `ClipTextEncoder` runs it on the same kernels (fused-QKV GEMM, the causal
+self-attention kernel of the LM layers with the attention mask as key mask, add+LayerNorm, quick-GELU epilogue) at its
+padded length -- CLIP texts are at most 77 tokens.
+
+Forward only, no autograd (the encoders are frozen, reference :922-934).  An architecture none of these cover
+(`supports()` is False: relative position embeddings, exotic activations) is an error at construction time unless the caller
+opts into the HF forward explicitly (`args.allow_hf_encoder_forward`); inputs the kernels cannot take (CPU tensors, a sequence
+whose first token is masked) raise.
 """
 import math
 
@@ -209,3 +215,67 @@ class PackedVisionEncoder:
             nxt = layers[li + 1].layer_norm1
             x, y = ops.add_layer_norm(f2, x, nxt.weight, nxt.bias, eps, return_sum=True)
         return ops.layer_norm(x.index_select(0, first_rows), core.post_layernorm.weight, core.post_layernorm.bias, eps)
+
+
+class ClipTextEncoder:
+    """CLIP text tower (`CLIPTextModel`): `pooler_output` = final_layer_norm(hidden)[EOS position] for [n, L] id / mask rows
+    (transformers CLIPTextTransformer.forward).  Causal attention + right padding: a valid token never sees a pad token, so the
+    valid rows equal HF's; pad rows are computed (L <= 77) and never read."""
+
+    def __init__(self, model):
+        self.model = model
+        self._fused = _Fused()
+
+    @staticmethod
+    def _core(model):
+        return getattr(model, "text_model", model)
+
+    @staticmethod
+    def supports(model):
+        core = ClipTextEncoder._core(model)
+        cfg = getattr(model, "config", None)
+        if cfg is None or not all(hasattr(core, a) for a in ("embeddings", "encoder", "final_layer_norm")):
+            return False
+        emb = core.embeddings
+        if not all(hasattr(emb, a) for a in ("token_embedding", "position_embedding")) or not hasattr(core.encoder, "layers"):
+            return False
+        if not isinstance(cfg.hidden_act, str) or cfg.hidden_act not in ops.ACT_CODES:
+            return False
+        D = cfg.hidden_size // cfg.num_attention_heads
+        return D in _HEAD_DIMS and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0
+
+    @torch.no_grad()
+    def pooled(self, ids, am):
+        core = self._core(self.model)
+        cfg = self.model.config
+        if not ids.is_cuda:
+            raise RuntimeError("ClipTextEncoder: GPU tensors only (mmgl_amd has no CPU path)")
+        n, L = ids.shape
+        hid, H, eps = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps
+        emb = core.embeddings
+        if n == 0:
+            return ids.new_zeros(0, hid, dtype=emb.token_embedding.weight.dtype)
+        x = (emb.token_embedding.weight.index_select(0, ids.reshape(-1)).view(n, L, hid) + emb.position_embedding.weight[:L]).reshape(n * L, hid)
+        layers = list(core.encoder.layers)
+        fused = self._fused.get([(l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj) for l in layers], 1.0 / math.sqrt(hid // H))
+        act = ops.ACT_CODES[cfg.hidden_act]
+        amc = am.contiguous()
+        y = ops.layer_norm(x, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, eps) if layers else None
+        for li, layer in enumerate(layers):
+            qkv = ops.gemm_nt(y, *fused[li])
+            ctx = ops.selfattn_core_fused(qkv.view(n, L, 3 * hid), amc, H).reshape(n * L, hid)
+            a = ops.gemm_nt(ctx, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias)
+            x, y2 = ops.add_layer_norm(a, x, layer.layer_norm2.weight, layer.layer_norm2.bias, eps, return_sum=True)
+            f = ops.gemm_nt(y2, layer.mlp.fc1.weight, layer.mlp.fc1.bias, act=act)
+            f2 = ops.gemm_nt(f, layer.mlp.fc2.weight, layer.mlp.fc2.bias)
+            nxt = layers[li + 1].layer_norm1 if li + 1 < len(layers) else core.final_layer_norm
+            x, y = ops.add_layer_norm(f2, x, nxt.weight, nxt.bias, eps, return_sum=True)
+        h = y if layers else ops.layer_norm(x, core.final_layer_norm.weight, core.final_layer_norm.bias, eps)
+        # the EOS position: transformers takes argmax(ids) for the legacy eos_token_id == 2 configs (the EOS id is the largest of
+        # CLIP's vocabulary), else the first position holding eos_token_id
+        eos_id = getattr(cfg, "eos_token_id", 2)
+        if eos_id == 2:
+            pos = ids.argmax(dim=-1)
+        else:
+            pos = (ids == eos_id).int().argmax(dim=-1)
+        return h.view(n, L, hid)[torch.arange(n, device=ids.device), pos]

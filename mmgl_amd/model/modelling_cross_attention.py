@@ -37,7 +37,7 @@ from transformers.activations import ACT2FN
 from transformers.modeling_outputs import BaseModelOutputWithPast, CausalLMOutputWithPast
 
 from .. import ops
-from .encoders import PackedTextEncoder, PackedVisionEncoder
+from .encoders import ClipTextEncoder, PackedTextEncoder, PackedVisionEncoder
 
 CROSS_MODES = ("cross_attention", "embedding")
 
@@ -845,7 +845,19 @@ class CrossAttentionModel(nn.Module):
         # packed (padding-free) HIP forward of the frozen encoders; the HF modules stay the owners of the weights
         self.packed_encoders = getattr(args, "packed_encoders", True)
         self._packed_text = PackedTextEncoder(self.text_model) if (self.text_model is not None and PackedTextEncoder.supports(self.text_model)) else None
+        self._clip_text = ClipTextEncoder(self.text_model) if (self.text_model is not None and ClipTextEncoder.supports(self.text_model)) else None
         self._packed_visual = PackedVisionEncoder(self.visual_model) if (self.visual_model is not None and PackedVisionEncoder.supports(self.visual_model)) else None
+        # an encoder architecture none of the HIP forwards cover runs its HF forward (library GEMMs, SDPA) only when the caller asked
+        # for exactly that; silently measuring / training on a different code path is what this refuses
+        self.allow_hf_encoder_forward = bool(getattr(args, "allow_hf_encoder_forward", False)) or not self.packed_encoders
+        if not self.allow_hf_encoder_forward:
+            if self.text_model is not None and self._packed_text is None and self._clip_text is None:
+                raise ValueError(f"text_model {type(self.text_model).__name__}: no HIP forward for this architecture (RoBERTa/BERT-style "
+                                 "absolute-position encoders and CLIP's text tower are covered); set args.allow_hf_encoder_forward = True "
+                                 "to run the HuggingFace forward instead")
+            if self.visual_model is not None and self._packed_visual is None:
+                raise ValueError(f"visual_model {type(self.visual_model).__name__}: no HIP forward for this architecture (CLIP ViT is covered); "
+                                 "set args.allow_hf_encoder_forward = True to run the HuggingFace forward instead")
 
         if self.args.freeze_lm:
             print("Freezing the LM.")
@@ -897,9 +909,11 @@ class CrossAttentionModel(nn.Module):
             if rows is not None:
                 ids, am = ids.index_select(0, rows), am.index_select(0, rows)
             is_clip = "clip" in self.args.text_model
-            if self.packed_encoders and self._packed_text is not None and not is_clip:
+            if self.packed_encoders and is_clip and self._clip_text is not None:
+                enc = self._clip_text.pooled(ids, am)
+            elif self.packed_encoders and self._packed_text is not None and not is_clip:
                 enc = self._packed_text.cls(ids, am, lens_host)
-            else:               # architectures without a packed HIP forward (CLIP's text tower): the HF module, length-bucketed
+            else:               # allow_hf_encoder_forward (or packed_encoders off): the HF module, length-bucketed
                 enc = encode_text_bucketed(self.text_model, ids, am, 1 if is_clip else self.text_length_buckets, use_pooler_output=is_clip)
             if rows is not None:
                 full = enc.new_zeros(batch_size * neighbor_num, enc.shape[-1])

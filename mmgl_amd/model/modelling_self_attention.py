@@ -194,6 +194,9 @@ class SelfAttentionModel(nn.Module):
             return None
         cache = self.__dict__.setdefault("_packed_cache", {})
         if id(model) not in cache:
+            if not cls.supports(model) and not getattr(self.args, "allow_hf_encoder_forward", False):
+                raise ValueError(f"{type(model).__name__}: no HIP forward for this encoder architecture ({cls.__name__} does not cover it); "
+                                 "set args.allow_hf_encoder_forward = True to run the HuggingFace forward instead")
             cache[id(model)] = cls(model) if cls.supports(model) else None
         return cache[id(model)]
 

@@ -26,7 +26,7 @@ class _XAttnCore(torch.autograd.Function):
         out = torch.empty_like(q)
         lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=q.device)
         _lib.call("mmgl_xattn_fwd", dict(B=B, H=num_heads, T=T, S=S, D=D, esize=q.element_size()), ptr(q), ptr(k), ptr(v), ptr(key_valid), ptr(out), ptr(lse), B, num_heads, T, S, D,
-                                   0.0, 0, 0, dtype_code(q), stream_ptr())
+                                   dtype_code(q), stream_ptr())
         ctx.save_for_backward(q, k, v, key_valid, lse)
         ctx.num_heads = num_heads
         return out

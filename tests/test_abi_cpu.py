@@ -45,11 +45,11 @@ def test_argument_validation_error_codes():
     from mmgl_amd import _lib
     L = _lib.lib()
     # null pointers / bad sizes are rejected before any launch (safe without a GPU)
-    assert L.mmgl_xattn_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 64, 0.0, 0, 0, 0, None) == 1
+    assert L.mmgl_xattn_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 64, 0, None) == 1
     assert b"null" in L.mmgl_last_error()
-    assert L.mmgl_xattn_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 48, 0.0, 0, 0, 0, None) == 2     # head_dim
-    assert L.mmgl_xattn_fwd(None, None, None, None, None, None, 1, 1, 8, 300, 64, 0.0, 0, 0, 0, None) == 2   # S > 256
-    assert L.mmgl_xattn_fwd(None, None, None, None, None, None, 0, 1, 8, 8, 64, 0.0, 0, 0, 0, None) == 1
+    assert L.mmgl_xattn_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 48, 0, None) == 2     # head_dim
+    assert L.mmgl_xattn_fwd(None, None, None, None, None, None, 1, 1, 8, 300, 64, 0, None) == 2   # S > 256
+    assert L.mmgl_xattn_fwd(None, None, None, None, None, None, 0, 1, 8, 8, 64, 0, None) == 1
     assert L.mmgl_linear_fwd(None, None, None, None, 4, 4, 4, 0, 1.0, 1, None) == 1
     assert L.mmgl_xattn_bwd_workspace(4, 32, 640, 64, 64) > 4 * 32 * 640 * 4
     assert L.mmgl_linear_wgrad_workspace(44, 8192, 768, 1) >= (8192 + 768) * 48 * 2

@@ -196,3 +196,50 @@ def test_packed_text_encoder_ignores_padding_width():
     a = enc.cls(ids.cuda(), am.cuda())
     b = enc.cls(wide_ids.cuda(), wide_am.cuda())
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("hidden,heads,layers,inter,eos", [(64, 4, 3, 128, 2), (512, 8, 2, 2048, 119)])
+def test_clip_text_encoder_matches_hf(dtype, tol, hidden, heads, layers, inter, eos):
+    """CLIP's text tower (reference model/modelling_cross_attention.py:918-921 accepts a CLIPTextModel as text_model): causal
+    pre-LN encoder, pooled output = final_layer_norm(h)[EOS position], on the HIP kernels (no HF / SDPA / library-GEMM forward).
+    eos_token_id 2 = the legacy argmax(ids) rule, otherwise the first position holding the EOS id (CLIP ViT-B/32 dims: 512 x 8)."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from mmgl_amd.model.encoders import ClipTextEncoder
+    L, vocab = 24, 120
+    cfg = CLIPTextConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=heads,
+                         max_position_embeddings=L, hidden_act="quick_gelu", pad_token_id=1, bos_token_id=0, eos_token_id=eos)
+    torch.manual_seed(13)
+    model = CLIPTextModel(cfg).eval().to(dtype).cuda()
+    assert ClipTextEncoder.supports(model)
+    gen = torch.Generator().manual_seed(4)
+    n = 7
+    lens = torch.randint(3, L + 1, (n,), generator=gen)
+    lens[0] = L
+    ids = torch.randint(3, vocab - 1, (n, L), generator=gen)
+    am = (torch.arange(L)[None] < lens[:, None]).long()
+    ids = torch.where(am.bool(), ids, torch.full_like(ids, 1))
+    ids[:, 0] = 0
+    ids[torch.arange(n), lens - 1] = vocab - 1 if eos == 2 else eos      # the EOS token closes every text (largest id of the vocabulary)
+    ids, am = ids.cuda(), am.cuda()
+    with torch.no_grad():
+        ref = model(input_ids=ids, attention_mask=am).pooler_output
+    got = ClipTextEncoder(model).pooled(ids, am)
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < tol
+
+
+def test_unsupported_encoder_architecture_raises_instead_of_running_hf():
+    """An encoder none of the HIP forwards cover must not run its HuggingFace forward silently (it did: round 2)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import mpt_args, tiny_clip_vision_config, tiny_opt_config
+    from transformers import RobertaConfig
+    from mmgl_amd.model import CrossAttentionModel
+    rel = RobertaConfig(vocab_size=128, hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64, max_position_embeddings=40,
+                        pad_token_id=1, type_vocab_size=1, position_embedding_type="relative_key")
+    with pytest.raises(ValueError, match="no HIP forward"):
+        CrossAttentionModel(mpt_args(context="all"), tokenizer=None, lm_config=tiny_opt_config(), text_config=rel, visual_config=tiny_clip_vision_config())
+    args = mpt_args(context="all")
+    args.allow_hf_encoder_forward = True
+    CrossAttentionModel(args, tokenizer=None, lm_config=tiny_opt_config(), text_config=rel, visual_config=tiny_clip_vision_config())

@@ -35,7 +35,7 @@ def run(B, H=32, T=640, S=64, D=64, dtype=torch.bfloat16, iters=200):
     ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
     code = _lib.dtype_code(q)
     st = stream_ptr()
-    fwd = lambda: L.mmgl_xattn_fwd(ptr(q), ptr(k), ptr(v), ptr(valid), ptr(out), ptr(lse), B, H, T, S, D, 0.0, 0, 0, code, st)
+    fwd = lambda: L.mmgl_xattn_fwd(ptr(q), ptr(k), ptr(v), ptr(valid), ptr(out), ptr(lse), B, H, T, S, D, code, st)
     bwd = lambda: L.mmgl_xattn_bwd(ptr(w), ptr(q), ptr(k), ptr(v), ptr(lse), ptr(valid), ptr(dq), ptr(dk), ptr(dv), ptr(ws), nws, B, H, T, S, D, code, st)
     for _ in range(5):
         assert fwd() == 0 and bwd() == 0
