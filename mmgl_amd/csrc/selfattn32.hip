@@ -43,6 +43,15 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef SA32_NS64
 #define SA32_NS64 2               // ring slots at head_dim 64 (3: two tiles in flight, 3 workgroups per CU; 2: one tile, 4 workgroups)
 #endif
+#ifndef SA32_NS_DQ
+#define SA32_NS_DQ 2              // ring slots of the dQ kernel (K / V tiles)
+#endif
+#ifndef SA32_NS_DKV
+#define SA32_NS_DKV 2             // ring slots of the dK / dV kernel (Q / dO tiles + row statistics)
+#endif
+#ifndef SA32_TRACE
+#define SA32_TRACE 0              // timing experiments only: wall-clock stamps of every workgroup of the forward kernel (MMGL_SA32_TRACE = device pointer)
+#endif
 #ifndef SA32_VEARLY
 #define SA32_VEARLY 1             // V^T fragments requested before the softmax arithmetic (their latency hides under it)
 #endif
@@ -73,6 +82,7 @@ struct SA32Args {
     float* lse;                // [B, H, T] or null
     const int* cu;             // packed mode: sequence i owns rows cu[i] .. cu[i+1]-1; null = batch mode
     int B, H, T, P, nqb, ldq, ldk, ldo, q_rows;
+    long long* trace;          // SA32_TRACE builds (timing experiments): 8 x int64 per workgroup
 };
 
 __device__ __forceinline__ f32x16 mma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
@@ -93,6 +103,9 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int key = lane & 31, hi = lane >> 5;
 
+#if SA32_TRACE
+    const long long tr0 = wall_clock64();
+#endif
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = vid / a.nqb;
     const int qblk = CAUSAL ? a.nqb - 1 - vid % a.nqb : vid % a.nqb;      // causal: longest (most key tiles) first
@@ -325,9 +338,16 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
 #pragma unroll
     for (int ks = 0; ks < G::NKS; ++ks) asm volatile("" ::"v"(qf[ks]));
     SA32_BARRIER();                                                     // the valid words are visible
+#if SA32_TRACE
+    const long long tr1 = wall_clock64();
+    long long tr2 = tr1;
+#endif
     uint64_t vm = vbits[0];
     int slot = 0, islot = PD % G::NS;
     for (int j = 0; j < ((SA32_ABLATE & 16) ? 0 : nkt); ++j) {
+#if SA32_TRACE
+        if (j == 1) tr2 = wall_clock64();
+#endif
         // tile j has landed (this wave's pieces: all but the NP * (tiles still in flight behind it) youngest loads), then everybody's
         if (PD >= 2 && j + 1 < nkt) {
             if (G::NP == 4) SA32_VMCNT(4); else SA32_VMCNT(8);
@@ -350,6 +370,9 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
     }
 
     // ---- epilogue: fold the lane pair's row sums, normalise, store O (16-byte stores after a v_permlane32_swap) and the LSE
+#if SA32_TRACE
+    const long long tr3 = wall_clock64();
+#endif
     {
         float lo, up;
         swap32(lsum, lo, up);
@@ -375,6 +398,16 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
             __builtin_amdgcn_raw_buffer_store_b128(val, ro, orow + (uint32_t)(32 * db + 8 * (c + hi)) * 2u, 0, ATTN_STORE_AUX);
         }
     if (a.lse && hi == 0 && trow < Tq) a.lse[(size_t)bh * a.T + trow] = (m2 + __builtin_amdgcn_logf(lsum)) * LN2;
+#if SA32_TRACE
+    if (a.trace && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the output stores have been acknowledged
+        long long* t = a.trace + (size_t)blockIdx.x * 8;
+        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = tr3; t[4] = wall_clock64();
+        t[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));           // HW_REG_HW_ID
+        t[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));          // HW_REG_XCC_ID
+        t[7] = nkt;
+    }
+#endif
 }
 
 
@@ -417,7 +450,7 @@ struct SA32BwdArgs {
 template <int D>
 __global__ __launch_bounds__(256, 2) void sa32_bwd_dq_kernel(SA32BwdArgs a) {
     typedef G32<D> G;
-    constexpr int NS = 2, PD = NS - 1;
+    constexpr int NS = SA32_NS_DQ, PD = NS - 1;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -592,7 +625,8 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dq_kernel(SA32BwdArgs a) {
     uint64_t vm = vbits[0];
     int slot = 0, islot = PD % NS;
     for (int j = 0; j < nkt; ++j) {
-        SA32_VMCNT(0);                                                  // NS = 2: one tile in flight
+        if (PD >= 2 && j + 1 < nkt) { if (G::NP == 4) SA32_VMCNT(4); else SA32_VMCNT(8); }       // tile j landed, tile j + 1 may be in flight
+        else SA32_VMCNT(0);
         SA32_BARRIER();
         if (j + PD < nkt) issue(j + PD, islot);
         const uint64_t vnext = vbits[min(j + 1, nkt - 1)];
@@ -635,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dq_kernel(SA32BwdArgs a) {
 template <int D> struct GB32 {
     typedef G32<D> G;
     static constexpr int SLOTB = 2 * G::TILEB + 1024;                    // Q tile, dO tile, lse[64], delta[64], padding
-    static constexpr int NS = 2;
+    static constexpr int NS = SA32_NS_DKV;
     static constexpr int LDS = NS * SLOTB;
     static constexpr int NPB = 2 * G::PIECES / 4 + 2;                    // LDS-DMA instructions per wave and tile
 };
@@ -697,7 +731,8 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_void*)(base + 2 * G::TILEB), 4, (uint32_t)lane * 4u, i * 256, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rdl, (lds_void*)(base + 2 * G::TILEB + 256), 4, (uint32_t)lane * 4u, i * 256, 0, 0);
     };
-    if (i0 < nqt) issue(i0, 0);
+#pragma unroll
+    for (int t = 0; t < PD; ++t) issue(i0 + t, t);                      // (a tile past the last query row reads as zeros)
 
     const int lds0 = (int)(unsigned)(size_t)(lds_void*)smem;
     const int rbase = rowfrag_base<D>(lane);
@@ -749,10 +784,14 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
             const bool diag = q0 + a.P < k0 + 31;                        // some (query, key) pair of this block with key > query + P
             const int c2 = krow - a.P - q0 - 4 * hi;                     // visible iff kreg(r) >= c2
 #pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], -LOG2E, kbias);
+            if (diag) {                                                  // wave-uniform branch: off-diagonal blocks run none of this
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = (kreg(r) >= c2) ? s[r] : -INFINITY;
+            }
+#pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float e = fmaf(s[r], -LOG2E, kbias);
-                if (diag) e = (kreg(r) >= c2) ? e : -INFINITY;
-                const float p = __builtin_amdgcn_exp2f(e);
+                const float p = __builtin_amdgcn_exp2f(s[r]);
                 s[r] = p;
                 dp[r] = p * dp[r];                                       // = -dS
             }
@@ -801,14 +840,16 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
         }
     };
 
-    int slot = 0;
+    int slot = 0, islot = PD % NS;
     for (int i = i0; i < nqt; ++i) {
-        SA32_VMCNT(0);                                                  // NS = 2: one tile in flight
+        if (PD >= 2 && i + 1 < nqt) { if (GB::NPB == 6) SA32_VMCNT(6); else SA32_VMCNT(10); }     // tile i landed, tile i + 1 may be in flight
+        else SA32_VMCNT(0);
         SA32_BARRIER();
-        if (i + 1 < nqt) issue(i + 1, slot ^ 1);
+        if (i + PD < nqt) issue(i + PD, islot);
         // this wave's keys are seen by some row of the tile iff its first key k0 <= last row + P
         if (wave_has_keys && k0 <= i * 64 + 63 + a.P) body(i, slot);
-        slot ^= 1;
+        slot = (slot + 1 == NS) ? 0 : slot + 1;
+        islot = (islot + 1 == NS) ? 0 : islot + 1;
     }
 
     // ---- epilogue: dK = -acc, dV rows (lane = key row: the forward kernel's output store)
@@ -850,7 +891,7 @@ template <int D, bool CAUSAL> int launch_fwd(const SA32Args& a, int nblocks, hip
 
 template <int D> int launch_bwd_dq(const SA32BwdArgs& a, hipStream_t st) {
     typedef G32<D> G;
-    constexpr int LDS = 2 * G::SLOTB + G::MAXT * 8;
+    constexpr int LDS = SA32_NS_DQ * G::SLOTB + G::MAXT * 8;
     auto kern = sa32_bwd_dq_kernel<D>;
     static bool configured = false;
     if (!configured) {
@@ -886,6 +927,9 @@ int sa32_fwd(const void* q, const void* k, const void* v, const uint8_t* valid, 
     SA32Args a{};
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.valid = valid; a.out = (bf16*)out; a.lse = lse; a.cu = nullptr;
     a.B = B; a.H = H; a.T = T; a.P = P; a.nqb = cdiv(T, 128); a.ldq = ldq; a.ldk = ldk; a.ldo = H * D; a.q_rows = T;
+#if SA32_TRACE
+    if (const char* e = getenv("MMGL_SA32_TRACE")) a.trace = (long long*)strtoull(e, nullptr, 0);
+#endif
     const int nblocks = B * H * a.nqb;
     return D == 64 ? launch_fwd<64, true>(a, nblocks, st) : launch_fwd<128, true>(a, nblocks, st);
 }
