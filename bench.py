@@ -249,6 +249,7 @@ def main():
 
     from mmgl_amd import _lib
     from mmgl_amd.distributed import DataParallelEngine
+    from mmgl_amd.language_modelling.run_generation import _summary_cross_entropy
     from mmgl_amd.model import CrossAttentionModel, SelfAttentionModel
     _lib.lib()                                        # fail loudly if the HIP extension is missing
 
@@ -298,7 +299,7 @@ def main():
     def step():
         out = model(**batch, logits_slice=summary)
         lg = out.logits.detach()
-        meter = torch.nn.functional.cross_entropy(lg.reshape(-1, lg.size(-1)).float(), batch["labels"][..., lin + 1:].reshape(-1), ignore_index=1).item()
+        meter = _summary_cross_entropy(lg, batch["labels"][..., lin + 1:], 1).item()
         last_meter[0] = meter
         out.loss.backward()
         engine.finish_backward()

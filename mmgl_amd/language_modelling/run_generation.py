@@ -248,6 +248,17 @@ def _summary_slices(args, logits, labels):
     return lg, lb
 
 
+def _summary_cross_entropy(lg, lb, pad_id):
+    """The running meter's loss over the summary positions (reference :473-480).  On the GPU: the HIP cross-entropy kernel straight on
+    the logits slice (one pass over 0.8 GB at B = 64 instead of an fp32 copy, a log-softmax and a gather: 0.9 ms per step)."""
+    lg2, lb1 = lg.reshape(-1, lg.size(-1)), lb.reshape(-1)
+    if lg2.is_cuda:
+        from .. import ops
+        with torch.no_grad():
+            return ops.cross_entropy(lg2.contiguous(), lb1.contiguous(), pad_id)
+    return nn.functional.cross_entropy(lg2.float(), lb1, ignore_index=pad_id)
+
+
 def _takes_logits_slice(model):
     from ..model.modelling_cross_attention import CrossAttentionModel
     return isinstance(model, CrossAttentionModel)
@@ -307,7 +318,7 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
                 lg, lb = outputs.logits.detach(), batch["labels"][..., (args.max_input_length + 1):]
             else:
                 lg, lb = _summary_slices(args, outputs.logits.detach(), batch["labels"])
-            summary_loss = nn.functional.cross_entropy(lg.reshape(-1, lg.size(-1)).float(), lb.reshape(-1), ignore_index=pad_id)
+            summary_loss = _summary_cross_entropy(lg, lb, pad_id)
             losses.update(summary_loss.item(), batch["input_ids"].size(0))
         else:
             losses.update(loss.item(), batch["input_ids"].size(0))

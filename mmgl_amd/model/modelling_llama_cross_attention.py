@@ -116,6 +116,11 @@ class LlamaNeighborLM(nn.Module):
                 m.weight.data.normal_(mean=0.0, std=std)
         self._frozen = [_FrozenLlamaLayer(layer, cfg) for layer in self.llama.model.layers]
         self._rope = None
+        # The rotary frequencies, kept OUT of the module's buffers: `model.bfloat16()` / `.to(torch.bfloat16)` (what run_generation.py
+        # does to the whole model, reference :304-307) casts HF's non-persistent `inv_freq` buffer as well, and positions x
+        # frequencies rounded to 8 bits are radians off at T = 2176 (a 4-layer model then drifts 6 % per layer from its fp32 self:
+        # tests/test_full_size_gpu.py found it).  A plain attribute is not touched by dtype casts.
+        self._inv_freq = self.llama.model.rotary_emb.inv_freq.detach().to(torch.float32).clone()
 
     def get_input_embeddings(self):
         return self.llama.get_input_embeddings()
@@ -123,9 +128,9 @@ class LlamaNeighborLM(nn.Module):
     def _cos_sin(self, T, device):
         """fp32 [T, D/2, 2] table of (cos, sin) for positions 0..T-1 from the HF rotary module's own inv_freq / scaling."""
         rot = self.llama.model.rotary_emb
-        key = (T, device, rot.inv_freq.data_ptr())
+        key = (T, device)
         if self._rope is None or self._rope[0] != key:
-            inv = rot.inv_freq.to(device=device, dtype=torch.float32)
+            inv = self._inv_freq.to(device=device)
             ang = torch.arange(T, device=device, dtype=torch.float32)[:, None] * inv[None, :]
             sc = float(getattr(rot, "attention_scaling", 1.0))
             self._rope = (key, torch.stack([ang.cos() * sc, ang.sin() * sc], dim=-1).contiguous())

@@ -157,7 +157,9 @@ def test_llama_config5_dims_one_layer_bf16():
     lm = lm.bfloat16().cuda().eval()
     with torch.no_grad():
         got = lm(input_ids=ids.cuda(), attention_mask=am.cuda(), neighbor_embeds=ne.cuda(), neighbor_attention_mask=valid.cuda()).logits
-        want = lm.llama.float()(input_ids=ids.cuda(), attention_mask=am.cuda()).logits          # HF forward, fp32, same (bf16-rounded) weights
+        hf = lm.llama.float()
+        hf.model.rotary_emb.inv_freq.copy_(lm._inv_freq)     # the bf16 cast above rounded HF's frequency buffer too: undo that (see LlamaNeighborLM.__init__)
+        want = hf(input_ids=ids.cuda(), attention_mask=am.cuda()).logits                          # HF forward, fp32, same (bf16-rounded) weights
     keep = am.bool().cuda()
     assert_close(got.float()[keep], want[keep], 3e-2, "config-5 dims: logits vs HF Llama (valid positions)")
     lm.llama.bfloat16()

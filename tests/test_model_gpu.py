@@ -250,14 +250,16 @@ def test_prefix_tuning_equals_hf_opt_with_past_key_values(pre_ln):
     assert_close(t_dev.grad, t_ref.grad, 5e-3, "d loss / d prefix table")
 
 
-def test_full_size_opt_1_3b_step_loss_matches_cpu_oracle():
-    """BASELINE.json config 3 at its real dimensions (OPT-1.3B, d = 2048, 24 + 4 layers, 11 + 5 neighbors, T = 640, roberta-base +
-    CLIP ViT-B/16 encoders; random init): the bf16 HIP forward of one synthetic sample against the fp32 CPU oracle of the same
-    weights and batch -- every kernel of the path at full size in one number.  Tolerance: bf16 rounding through 28 layers."""
+@pytest.mark.parametrize("name,nsamp", [("opt-1.3b", 1), ("opt-125m", 2)])
+def test_full_size_step_matches_cpu_oracle(name, nsamp):
+    """BASELINE.json config 3 (OPT-1.3B, d = 2048, 24 + 4 layers, 11 + 5 neighbors) and config 2 (OPT-125m, d = 768, 12 + 4 layers,
+    2 + 2 neighbors) at their real dimensions (T = 640, roberta-base + CLIP ViT-B/16 encoders; random init): logits, loss and
+    gradients of the HIP path (fp32, then bf16) on synthetic samples against the fp32 CPU oracle of the same weights and batch --
+    every kernel of the path at full size.  Tolerances: 1e-3 fp32 (BASELINE.json); bf16 rounding through all layers."""
     import bench
     from oracle import lm_ref, wrapper_ref
     from mmgl_amd.model import CrossAttentionModel
-    cfg = bench.CONFIGS["opt-1.3b"]
+    cfg = bench.CONFIGS[name]
     lm_cfg, txt_cfg, vis_cfg = bench.hf_configs(cfg)
     torch.manual_seed(1234)
     with torch.device("cpu"):
@@ -268,7 +270,7 @@ def test_full_size_opt_1_3b_step_loss_matches_cpu_oracle():
                 p.fill_(0.5)
     model.eval()
     batch, _ = bench.synthetic_batch(2, cfg, seed=99, device=torch.device("cpu"))
-    b = {k: v[:1] for k, v in batch.items() if k != "host_meta"}
+    b = {k: v[:nsamp] for k, v in batch.items() if k != "host_meta"}
     # oracle (fp32, CPU)
     torch.set_num_threads(min(32, torch.get_num_threads()))
     sd = {k: v.detach().float() for k, v in model.state_dict().items()}
@@ -310,7 +312,7 @@ def test_full_size_opt_1_3b_step_loss_matches_cpu_oracle():
     dev = model.to(torch.bfloat16).cuda()
     out = dev(**{k: v.cuda() for k, v in b.items()})
     out.loss.backward()
-    print(f"full-size config 3, one sample: HIP bf16 loss {float(out.loss):.5f} vs CPU oracle fp32 {float(ref_loss):.5f}")
+    print(f"full-size {name}, {nsamp} sample(s): HIP bf16 loss {float(out.loss):.5f} vs CPU oracle fp32 {float(ref_loss):.5f}")
     assert torch.isfinite(out.loss)
     assert abs(float(out.loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
     params = dict(dev.named_parameters())
