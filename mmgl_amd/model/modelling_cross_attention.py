@@ -218,6 +218,8 @@ class MPTAttention(nn.Module):
         else:
             if type(self.q_proj) is nn.Linear and self.q_proj.weight.requires_grad:
                 q = ops.linear(hidden_states, self.q_proj.weight, self.q_proj.bias, out_scale=self.scaling)
+            elif type(self.q_proj) is not nn.Linear and hasattr(self.q_proj, "lora_A"):
+                q = self.q_proj(hidden_states, out_scale=self.scaling)           # LoRA: the scaling rides in the GEMM epilogues
             else:
                 q = _lin(self.q_proj, hidden_states) * self.scaling
             o = ops.selfattn_core(q, _lin(self.k_proj, hidden_states), _lin(self.v_proj, hidden_states), attention_mask, H)

@@ -54,8 +54,10 @@ class LoRALinear(nn.Module):
     def bias(self):
         return self.base_layer.bias
 
-    def forward(self, x):
-        return ops.lora_linear(x, self.base_layer.weight, self.base_layer.bias, self.lora_A, self.lora_B, self.scaling)
+    def forward(self, x, out_scale=1.0):
+        """out_scale: a constant factor on the whole output (attention's D^-1/2 on an adapted q_proj), applied in the GEMM epilogues
+        instead of a separate pass over [B, T, d]."""
+        return ops.lora_linear(x, self.base_layer.weight, self.base_layer.bias, self.lora_A, self.lora_B, self.scaling, out_scale)
 
 
 def inject_lora(model: nn.Module, r: int, alpha: float, dropout: float, targets=("q_proj", "v_proj", "q", "v")):

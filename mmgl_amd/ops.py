@@ -542,7 +542,7 @@ class _LoraLinearBig(torch.autograd.Function):
     per step came from autograd's bookkeeping around the composed form)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, lora_A, lora_B, scale):
+    def forward(ctx, x, weight, bias, lora_A, lora_B, scale, out_scale=1.0):
         require_cuda(x, weight)
         K, N, r = x.shape[-1], weight.shape[0], lora_A.shape[0]
         rp = (-r) % 256
@@ -550,32 +550,32 @@ class _LoraLinearBig(torch.autograd.Function):
         B_pad = F.pad(lora_B.detach().to(x.dtype), (0, rp)).contiguous()                # [N, 256]
         x2 = x.reshape(-1, K).contiguous()
         xa = gemm_nt(x2, A_pad)                                                         # [M, 256]
-        delta = gemm_nt(xa, B_pad, out_scale=scale)                                     # [M, N]
+        delta = gemm_nt(xa, B_pad, out_scale=scale * out_scale)                         # [M, N]  (out_scale: attention's D^-1/2 on q_proj)
         w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
         b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
         out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
-        gemm_nt(x2, w.contiguous(), b, residual=delta, out=out.view(-1, N))
+        gemm_nt(x2, w.contiguous(), b, residual=delta, out_scale=out_scale, out=out.view(-1, N))
         ctx.save_for_backward(x2, xa, weight, A_pad, B_pad)
-        ctx.meta = (x.shape, float(scale), r, lora_A.dtype, lora_B.dtype)
+        ctx.meta = (x.shape, float(scale), r, lora_A.dtype, lora_B.dtype, float(out_scale))
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x2, xa, weight, A_pad, B_pad = ctx.saved_tensors
-        xshape, scale, r, adt, bdt = ctx.meta
+        xshape, scale, r, adt, bdt, os_ = ctx.meta
         N = weight.shape[0]
         g = dy.reshape(-1, N).contiguous()
-        dxa = gemm_nt(g, B_pad.t().contiguous(), out_scale=scale)                       # (dy B) * scale  [M, 256]
-        dB = _wgrad_only(g, xa, B_pad, scale) if ctx.needs_input_grad[4] else None      # [N, 256]
+        dxa = gemm_nt(g, B_pad.t().contiguous(), out_scale=scale * os_)                 # (dy B) * scale  [M, 256]
+        dB = _wgrad_only(g, xa, B_pad, scale * os_) if ctx.needs_input_grad[4] else None      # [N, 256]
         dA = _wgrad_only(dxa, x2, A_pad, 1.0) if ctx.needs_input_grad[3] else None      # [256, K]
         dx = None
         if ctx.needs_input_grad[0]:
-            dx0 = frozen_dgrad(g, weight)                                               # dy W
-            dx = gemm_nt(dxa, A_pad.t().contiguous(), residual=dx0).view(xshape)        # + (dy B) A in the epilogue
-        return (dx, None, None, None if dA is None else dA[:r].to(adt), None if dB is None else dB[:, :r].contiguous().to(bdt), None)
+            low = gemm_nt(dxa, A_pad.t().contiguous())                                  # (dy B) A  [M, K]
+            dx = frozen_dgrad(g, weight, out_scale=os_, residual=low).view(xshape)      # dy W * out_scale + ... in the epilogue
+        return (dx, None, None, None if dA is None else dA[:r].to(adt), None if dB is None else dB[:, :r].contiguous().to(bdt), None, None)
 
 
-def lora_linear(x, weight, bias, lora_A, lora_B, scale):
+def lora_linear(x, weight, bias, lora_A, lora_B, scale, out_scale=1.0):
     """x W^T + b + scale * (x A^T) B^T with a frozen base weight (peft LoRA semantics, lora_dropout = 0).
     Large bf16 shapes: the base product runs on the persistent ping-pong GEMM with the low-rank update
     delta = (x A^T)(scale B)^T -- two skinny, HBM-bound GEMMs -- added in its epilogue; backward = the frozen dgrad GEMM plus
@@ -589,14 +589,17 @@ def lora_linear(x, weight, bias, lora_A, lora_B, scale):
         # (x A^T) B^T, and in backward dy B, (dy B) A, (dy B)^T x, dy^T (x A^T) -- is then a 256-wide GEMM the large-tile kernels
         # (and their K splits) carry, instead of a 16-wide one on a handful of workgroups
         if _LORA_ONE_NODE and x.dtype == torch.bfloat16 and K % 8 == 0 and N % 8 == 0:
-            return _LoraLinearBig.apply(x, weight, bias, lora_A, lora_B, float(scale))
+            return _LoraLinearBig.apply(x, weight, bias, lora_A, lora_B, float(scale), float(out_scale))
+        if out_scale != 1.0:
+            return lora_linear(x, weight, bias, lora_A, lora_B, scale) * out_scale
         rp = (-lora_A.shape[0]) % 256
         A_pad = F.pad(lora_A, (0, 0, 0, rp)) if rp else lora_A
         B_pad = F.pad(lora_B, (0, rp)) if rp else lora_B
         xa = linear(x, A_pad)                                      # [.., 256]
         delta = linear(xa, B_pad, out_scale=scale)                 # [.., N]
         return frozen_linear(x, weight, bias, residual=delta)
-    return _LoraLinear.apply(x, weight, bias, lora_A, lora_B, float(scale))
+    y = _LoraLinear.apply(x, weight, bias, lora_A, lora_B, float(scale))
+    return y if out_scale == 1.0 else y * out_scale
 
 
 # ------------------------------------------------------------------------------------------ neighbor interleave
@@ -878,7 +881,7 @@ def _gemm_nt_padded(x2, w, bias=None, zmask=None, act=0, K=None):
     return y[:, :N].contiguous() if pn else y
 
 
-def frozen_dgrad(g, weight, zmask=None, out=None, bits=None):
+def frozen_dgrad(g, weight, zmask=None, out=None, bits=None, out_scale=1.0, residual=None):
     """dx[M,K] = g[M,N] @ W[N,K] for a frozen W  ==  an NT GEMM against the cached W^T [K, Npad].  The contraction length is
     padded to a multiple of 128 with zero columns of W^T (lm_head: N = vocab = 50272) and g is read with its own row stride.
     No autograd."""
@@ -894,7 +897,11 @@ def frozen_dgrad(g, weight, zmask=None, out=None, bits=None):
     if bits is not None:                                      # the ReLU mask as bits (see _FrozenLinear): `out` carries the row pitch
         return gemm_nt_masked(g, wt, bits, out, K=kk)
     if out is not None and kk % (8 if g.dtype == torch.bfloat16 else 4) == 0 and K % 8 == 0:
-        return gemm_nt(g, wt, zmask=zmask, K=kk, out=out)
+        return gemm_nt(g, wt, zmask=zmask, residual=residual, out_scale=out_scale, K=kk, out=out)
+    if residual is not None or out_scale != 1.0:
+        if kk % (8 if g.dtype == torch.bfloat16 else 4) or K % 8:
+            raise ValueError("frozen_dgrad: out_scale / residual need 16-byte aligned feature counts")
+        return gemm_nt(g, wt, zmask=zmask, residual=residual, out_scale=out_scale, K=kk)
     dx = _gemm_nt_padded(g, wt, zmask=zmask, K=kk)
     if out is not None:
         out.copy_(dx)

@@ -320,10 +320,11 @@ def test_lora_linear(dtype, M, N, K):
     w = torch.randn(M, N, generator=g) * (200.0 / M) ** 0.5          # keep dA / dB (sums over M rows) O(1)
     xd, Ad, Bd = dev(x, dtype), dev(A, dtype), dev(Bm, dtype)
     Wd, bd = W.to(dtype).cuda(), b.to(dtype).cuda()
-    y = ops.lora_linear(xd, Wd, bd, Ad, Bd, s)
+    os_ = 0.125 if M % 2 == 0 else 1.0                                # the attention scaling of an adapted q_proj, in the epilogues
+    y = ops.lora_linear(xd, Wd, bd, Ad, Bd, s, os_)
     (y * w.to(dtype).cuda()).sum().backward()
     xr, Ar, Br = (t.detach().float().requires_grad_() for t in (xd, Ad, Bd))       # fp32 torch reference (on the GPU: size)
-    yr = F.linear(xr, Wd.float(), bd.float()) + s * (xr @ Ar.t()) @ Br.t()
+    yr = (F.linear(xr, Wd.float(), bd.float()) + s * (xr @ Ar.t()) @ Br.t()) * os_
     (yr * w.to(dtype).float().cuda()).sum().backward()
     t = tol(dtype, 1e-4, 3e-2)
     assert_close(y.float(), yr, t, "y")
