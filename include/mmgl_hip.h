@@ -247,7 +247,9 @@ int mmgl_adamw_step(void* param, float* master, const void* grad, float* exp_avg
  *           backward is folded into the epilogue).
  *   bias [N], residual [M,N], zmask [M,N] may be NULL; act: 0 none, 1 relu, 2 gelu (erf), 3 quick_gelu, 4 gelu (tanh).
  * bf16 shapes with K % 128 == 0, K >= 256, N % 16 == 0 and enough 256x256 tiles run on the persistent ping-pong kernel
- * (gemm8p.hip; mmgl_gemm_nt_fast reports that); anything else is composed from mmgl_linear_fwd + the elementwise kernels.
+ * (gemm8p.hip; mmgl_gemm_nt_fast returns 1), other bf16 shapes with K % 64 == 0, N % 8 == 0 on the 128x128 kernel (gemm_mid.hip;
+ * returns 2): both take strided operands and apply the whole epilogue in the kernel.  Anything else (returns 0) is composed from
+ * mmgl_linear_fwd + the elementwise kernels.
  * ldx / ldw / ldy: row strides in elements (residual and zmask share ldy); the composed path needs dense operands.
  * mmgl_relu_bwd: out = dy * (y > 0), the backward of a stand-alone ReLU epilogue (in place allowed). */
 int mmgl_gemm_nt_fast(int M, int N, int K, int ldx, int ldw, int ldy, int dtype);

@@ -322,6 +322,10 @@ inline int tune_gemm_8p_min_tiles() {
     return v;
 }
 
+inline int tune_gemm_mid() {
+    static const int v = [] { const char* e = getenv("MMGL_GEMM_MID"); return e ? atoi(e) : 1; }();
+    return v;
+}
 inline int tune_gemm_big() {
     static const int v = [] { const char* e = getenv("MMGL_GEMM_BIG"); return e ? atoi(e) : 1; }();
     return v;
@@ -419,6 +423,13 @@ int launch_gemm(const T* X, const T* W, T* Y, const T* bias, int M, int N, int K
             MMGL_CHECK_LAUNCH("gemm_nt256");
             if (zmask_done) *zmask_done = zmask != nullptr;
             return MMGL_OK;
+        }
+    }
+    if constexpr (sizeof(T) == 2) {
+        // 128x128 tiles, two workgroups per CU (gemm_mid.hip): outputs of too few 256x256 tiles for the persistent kernel
+        if (!X2 && !accumulate && tune_gemm_mid() && gemm_mid_supported(M, N, K, K, K, N)) {
+            if (zmask_done) *zmask_done = zmask != nullptr;
+            return launch_gemm_mid((const bf16*)X, K, (const bf16*)W, K, (bf16*)Y, N, (const bf16*)bias, nullptr, (const bf16*)zmask, M, N, K, act, scale, st);
         }
     }
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
@@ -1271,9 +1282,14 @@ extern "C" int mmgl_activation_fwd(const void* x, void* y, size_t n, int act, in
 extern "C" int mmgl_gated_residual_fwd(const void* residual, const void* x, const float* gate, void* y, size_t n, float p_drop,
                                        uint64_t seed, int dtype, void* stream);
 
-extern "C" int mmgl_gemm_nt_fast(int M, int N, int K, int ldx, int ldw, int ldy, int dtype) {
+static bool gemm_nt_on_8p(int M, int N, int K, int ldx, int ldw, int ldy, int dtype) {
     return dtype == MMGL_BF16 && tune_gemm_8p() && gemm8p_supported(M, N, K, ldx, ldw, ldy) &&
            (cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles() || gemm8p_use_splits(M, N, K));
+}
+// 1: the persistent 256x256 kernel, 2: the 128x128 kernel (both: strided operands, whole epilogue in the kernel), 0: composed path
+extern "C" int mmgl_gemm_nt_fast(int M, int N, int K, int ldx, int ldw, int ldy, int dtype) {
+    if (gemm_nt_on_8p(M, N, K, ldx, ldw, ldy, dtype)) return 1;
+    return (dtype == MMGL_BF16 && tune_gemm_mid() && gemm_mid_supported(M, N, K, ldx, ldw, ldy)) ? 2 : 0;
 }
 
 extern "C" size_t mmgl_gemm_nt_workspace(int M, int N, int K, int ldx, int ldw, int ldy, int dtype) {
@@ -1292,9 +1308,12 @@ extern "C" int mmgl_gemm_nt(const void* x, int ldx, const void* W, int ldw, cons
     MMGL_CHECK_ARG(ldx + 127 >= K && ldw >= K && ldy >= N, "mmgl_gemm_nt: leading dimensions (%d, %d, %d) smaller than the rows (K=%d, N=%d)", ldx, ldw, ldy, K, N);
     hipStream_t st = (hipStream_t)stream;
     // few-tile shapes run as K-split work items when the caller brought mmgl_gemm_nt_workspace() bytes, unsplit otherwise
-    if (mmgl_gemm_nt_fast(M, N, K, ldx, ldw, ldy, dtype))
+    if (gemm_nt_on_8p(M, N, K, ldx, ldw, ldy, dtype))
         return launch_gemm8p((const bf16*)x, ldx, (const bf16*)W, ldw, (bf16*)y, ldy, (const bf16*)bias, (const bf16*)residual,
                              (const bf16*)zmask, M, N, K, act, out_scale, st, (float*)workspace, workspace_bytes);
+    if (dtype == MMGL_BF16 && tune_gemm_mid() && gemm_mid_supported(M, N, K, ldx, ldw, ldy))
+        return launch_gemm_mid((const bf16*)x, ldx, (const bf16*)W, ldw, (bf16*)y, ldy, (const bf16*)bias, (const bf16*)residual,
+                               (const bf16*)zmask, M, N, K, act, out_scale, st);
     if (ldx != K || ldw != K || ldy != N)
         MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "mmgl_gemm_nt: strided operands (ld %d %d %d) need the bf16 fast path (K %% 128 == 0, N %% 16 == 0, "
                   ">= %d tiles of 256x256); got M=%d N=%d K=%d dtype=%d", ldx, ldw, ldy, tune_gemm_8p_min_tiles(), M, N, K, dtype);

@@ -18,3 +18,8 @@ inline size_t gemm8p_bits_bytes(int M, int N) { return (size_t)cdiv(M, 256) * cd
 int gemm8p_tt_splits(int RA, int RB, int M);
 int launch_gemm8p_tt(const bf16* A, int lda, const bf16* B, int ldb, bf16* Out, float* part, int RA, int RB, int M, int nsplit, float scale,
                      int accumulate, hipStream_t st);
+
+// 128x128 tiles, two workgroups per CU (gemm_mid.hip): few-tile outputs.  Same epilogue contract as launch_gemm8p.
+bool gemm_mid_supported(int M, int N, int K, int ldx, int ldw, int ldy);
+int launch_gemm_mid(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, const bf16* resid, const bf16* zmask,
+                    int M, int N, int K, int act, float scale, hipStream_t st);

@@ -761,7 +761,9 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
         const char* Qs = smem + slot * GB::SLOTB;
         const char* Gs = Qs + G::TILEB;
         const char* St = Qs + 2 * G::TILEB;
-        bf16x8 pf[2][2], dsf[2][2];
+        // per 32-query block: S^T / dP^T (lse, delta ride in as C), P and -dS, then dV^T += dO^T P and (-dK^T) += Q^T (-dS) through
+        // transposed reads of that block's dO / Q rows, one 32-channel block of one operand at a time (reads of step + 1 under the MFMAs of step)
+        const int qslot = tbase + slot * GB::SLOTB, gslot = qslot + G::TILEB;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 s, dp;
@@ -775,10 +777,23 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
 #pragma unroll
             for (int ks = 0; ks < G::NKS; ++ks) {
                 const bf16x8 qr = *(const bf16x8*)(Qs + qb * 32 * G::ROWB + (rbase ^ (ks << 5)));
-                const bf16x8 gr = *(const bf16x8*)(Gs + qb * 32 * G::ROWB + (rbase ^ (ks << 5)));
                 s = mma32(qr, kf[ks], s);
+            }
+#pragma unroll
+            for (int ks = 0; ks < G::NKS; ++ks) {
+                const bf16x8 gr = *(const bf16x8*)(Gs + qb * 32 * G::ROWB + (rbase ^ (ks << 5)));
                 dp = mma32(gr, vf[ks], dp);
             }
+            bf16x4 fa[2][2][2];
+            auto treads = [&](int step, bf16x4 (&f)[2][2]) __attribute__((always_inline)) {     // step = 2 db + (0: dO, 1: Q)
+                const int ad0 = ((step & 1) ? qslot : gslot) ^ ((step >> 1) << 6), ad1 = ad0 ^ TRX<D>::value;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    SA32_TR_READ(f[jj][0], ad0, (32 * qb + 16 * jj) * G::ROWB);
+                    SA32_TR_READ(f[jj][1], ad1, (32 * qb + 16 * jj + 8) * G::ROWB);
+                }
+            };
+            treads(0, fa[0]);
             // s = lse - q.k, dp = delta - dO.v;  query of register r: 64 i + 32 qb + kreg(r) + 4 hi
             const int q0 = i * 64 + 32 * qb;
             const bool diag = q0 + a.P < k0 + 31;                        // some (query, key) pair of this block with key > query + P
@@ -795,48 +810,33 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
                 s[r] = p;
                 dp[r] = p * dp[r];                                       // = -dS
             }
+            bf16x8 pf[2], dsf[2];
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 f32x8 t, u;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { t[e] = s[8 * jj + e]; u[e] = dp[8 * jj + e]; }
-                pf[qb][jj] = __builtin_convertvector(t, bf16x8);
-                dsf[qb][jj] = __builtin_convertvector(u, bf16x8);
+                pf[jj] = __builtin_convertvector(t, bf16x8);
+                dsf[jj] = __builtin_convertvector(u, bf16x8);
             }
-        }
-        // dV^T += dO^T P, (-dK^T) += Q^T (-dS): transposed reads of the dO / Q tiles, one 32-channel block of one operand at a time
-        bf16x4 fa[2][2][2][2];
-        const int qslot = tbase + slot * GB::SLOTB, gslot = qslot + G::TILEB;
-        auto treads = [&](int step, bf16x4 (&f)[2][2][2]) __attribute__((always_inline)) {     // step = 2 db + (0: dO, 1: Q)
-            const int ad0 = ((step & 1) ? qslot : gslot) ^ ((step >> 1) << 6), ad1 = ad0 ^ TRX<D>::value;
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    SA32_TR_READ(f[qb][jj][0], ad0, (32 * qb + 16 * jj) * G::ROWB);
-                    SA32_TR_READ(f[qb][jj][1], ad1, (32 * qb + 16 * jj + 8) * G::ROWB);
+            for (int step = 0; step < 2 * G::NDB; ++step) {
+                bf16x4 (&f)[2][2] = fa[step & 1];
+                if (step + 1 < 2 * G::NDB) {
+                    treads(step + 1, fa[(step + 1) & 1]);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]));
                 }
-        };
-        treads(0, fa[0]);
-#pragma unroll
-        for (int step = 0; step < 2 * G::NDB; ++step) {
-            bf16x4 (&f)[2][2][2] = fa[step & 1];
-            if (step + 1 < 2 * G::NDB) {
-                treads(step + 1, fa[(step + 1) & 1]);
-                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]));
-            }
-            const int db = step >> 1;
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
+                const int db = step >> 1;
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    const bf16x4 x = f[qb][jj][0], y = f[qb][jj][1];
+                    const bf16x4 x = f[jj][0], y = f[jj][1];
                     const bf16x8 tf = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
-                    if (step & 1) dka[db] = mma32(tf, dsf[qb][jj], dka[db]);
-                    else dva[db] = mma32(tf, pf[qb][jj], dva[db]);
+                    if (step & 1) dka[db] = mma32(tf, dsf[jj], dka[db]);
+                    else dva[db] = mma32(tf, pf[jj], dva[db]);
                 }
+            }
         }
     };
 

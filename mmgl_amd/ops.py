@@ -584,7 +584,7 @@ def lora_linear(x, weight, bias, lora_A, lora_B, scale, out_scale=1.0):
     M = x.numel() // x.shape[-1]
     N, K = weight.shape
     if (not weight.requires_grad and (bias is None or not bias.requires_grad) and x.is_cuda
-            and lib().mmgl_gemm_nt_fast(M, N, K, K, K, N, dtype_code(x))):
+            and lib().mmgl_gemm_nt_fast(M, N, K, K, K, N, dtype_code(x)) == 1):
         # the rank is zero-padded to 256 (autograd slices the gradients back): every product of the low-rank path -- x A^T,
         # (x A^T) B^T, and in backward dy B, (dy B) A, (dy B)^T x, dy^T (x A^T) -- is then a 256-wide GEMM the large-tile kernels
         # (and their K splits) carry, instead of a 16-wide one on a handful of workgroups
@@ -919,7 +919,7 @@ def _ffn_pitch(M, N, K, dtype):
     if dtype != torch.bfloat16 or (N * 2) % 8192 or not _FFN_PITCH:
         return N
     P, L = N + 128, lib()
-    if L.mmgl_gemm_nt_fast(M, N, K, K, K, P, _lib.BF16) and L.mmgl_gemm_nt_fast(M, K, N, P, N, K, _lib.BF16):
+    if L.mmgl_gemm_nt_fast(M, N, K, K, K, P, _lib.BF16) == 1 and L.mmgl_gemm_nt_fast(M, K, N, P, N, K, _lib.BF16) == 1:
         return P
     return N
 

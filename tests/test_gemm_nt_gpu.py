@@ -47,8 +47,12 @@ CASES = [
     (2560, 8192, 2048, 1, True, False, False, 1.0),      # 320 tiles on 256 CUs: one round of whole tiles + the other 64 as 4 K-split items each
     (2570, 8200, 2048, 0, True, True, True, 0.5),        # the same with ragged last tile row / column (363 tiles), zmask + residual in the finish kernel
     (2560, 8192, 4096, 3, False, False, False, 1.0),     # hybrid plan, 8-way remainder capped by its K steps
-    (1024, 512, 256, 1, True, False, False, 1.0),        # small: composed path (128x128 kernel + elementwise)
-    (300, 96, 64, 2, True, True, True, 2.0),             # tiny, ragged K tile: composed path
+    (1024, 512, 256, 1, True, False, False, 1.0),        # few tiles: the 128x128 kernel (csrc/gemm_mid.hip)
+    (300, 96, 64, 2, True, True, True, 2.0),             # tiny, one K step, ragged rows and columns, every epilogue stage
+    (2560, 2048, 2048, 0, True, True, False, 1.0),       # out_proj at the reference's batch of 4: 320 tiles of 128x128, two workgroups per CU
+    (2563, 2056, 2048, 4, True, False, True, 0.5),       # the same, ragged last tile row / column
+    (333, 136, 192, 1, False, True, True, 1.0),          # three K steps, no bias
+    (2560, 2048, 1984, 3, True, False, False, 1.0),      # K a multiple of 64 only (31 steps): not the persistent kernel's
 ]
 
 
@@ -71,14 +75,17 @@ def test_gemm_nt_fast_path_is_selected():
     L = _lib.lib()
     assert L.mmgl_gemm_nt_fast(40960, 2048, 2048, 2048, 2048, 2048, _lib.BF16) == 1
     assert L.mmgl_gemm_nt_fast(40960, 2048, 2048, 2048, 2048, 2048, _lib.F32) == 0
-    assert L.mmgl_gemm_nt_fast(1024, 512, 256, 256, 256, 512, _lib.BF16) == 0          # too few tiles
-    assert L.mmgl_gemm_nt_fast(40960, 2048, 2000, 2000, 2000, 2048, _lib.BF16) == 0      # K % 128
+    assert L.mmgl_gemm_nt_fast(1024, 512, 256, 256, 256, 512, _lib.BF16) == 2          # too few 256x256 tiles: the 128x128 kernel
+    assert L.mmgl_gemm_nt_fast(2560, 2048, 2048, 2112, 2048, 2176, _lib.BF16) == 2       # ... which takes strided operands too
+    assert L.mmgl_gemm_nt_fast(40960, 2048, 1984, 1984, 1984, 2048, _lib.BF16) == 2      # K % 128 != 0, K % 64 == 0
+    assert L.mmgl_gemm_nt_fast(40960, 2048, 2000, 2000, 2000, 2048, _lib.BF16) == 0      # K % 64: composed path
 
 
-def test_gemm_nt_strided_operands():
-    """x and W as column slices of wider buffers (ldx, ldw > K), y into a column slice (ldy > N)."""
+@pytest.mark.parametrize("M,N,K", [(40960, 2048, 1024), (2563, 2048, 1024), (77, 72, 64)])
+def test_gemm_nt_strided_operands(M, N, K):
+    """x and W as column slices of wider buffers (ldx, ldw > K), y into a column slice (ldy > N): the persistent kernel and the
+    128x128 kernel."""
     from mmgl_amd import ops
-    M, N, K = 40960, 2048, 1024
     g = torch.Generator(device="cuda").manual_seed(3)
     xb = torch.randn(M, K + 256, device="cuda", generator=g).bfloat16()
     Wb = (torch.randn(N, K + 128, device="cuda", generator=g) * K ** -0.5).bfloat16()
@@ -88,6 +95,23 @@ def test_gemm_nt_strided_operands():
     want = x.float() @ W.float().t()
     assert (yb[:, 32:32 + N].float() - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2
     assert float(yb[:, :32].abs().max()) == 0 and float(yb[:, 32 + N:].abs().max()) == 0
+
+
+def test_gemm_nt_padded_contraction_on_the_128_kernel():
+    """K past x's row length against zero columns of W (mmgl_gemm_nt's contract, the lm_head dgrad's trick) on the 128x128 kernel:
+    a row's tail reads the head of the next row (times zero), the LAST row's tail must not read past the tensor (NaN planted there)."""
+    from mmgl_amd import ops
+    M, N, K0, K = 300, 136, 200, 256
+    g = torch.Generator(device="cuda").manual_seed(11)
+    buf = torch.full((M + 1, K0), float("nan"), device="cuda", dtype=torch.bfloat16)
+    buf[:M] = torch.randn(M, K0, device="cuda", generator=g).bfloat16()
+    x = buf[:M]
+    W = torch.zeros(N, K, device="cuda", dtype=torch.bfloat16)
+    W[:, :K0] = (torch.randn(N, K0, device="cuda", generator=g) * K0 ** -0.5).bfloat16()
+    y = ops.gemm_nt(x, W, K=K)
+    want = x.float() @ W[:, :K0].float().t()
+    assert bool(torch.isfinite(y).all())
+    assert (y.float() - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2
 
 
 @pytest.mark.parametrize("M,d,ffn", [(40960, 2048, 8192), (2560, 2048, 8192), (200, 64, 128)])
