@@ -187,7 +187,7 @@ def pmc_traffic(B, lm_cfg, cfg, dtype):
     """HBM bytes per launch of xattn_fwd_kernel from the committed PMC collection (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate passes, gfx950 x2 fetch correction applied: profiles/r<round>_pmc_xattn_*.json) when it was taken at this exact
     shape; None otherwise -- PMC counters cannot be read from inside this process."""
-    for rnd in ("r2", "r1"):                                 # the latest round's collection first
+    for rnd in ("r3", "r2", "r1"):                           # the latest round's collection first
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_xattn_B{B}_{dtype}.json")
         try:
             with open(path) as f:
