@@ -176,6 +176,8 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
     constexpr int PD = G::NS - 1;                                       // tiles in flight
 #pragma unroll
     for (int j = 0; j < PD; ++j) issue(j, j);                           // unconditional (a tile past the last key reads as zeros): hipcc's vmcnt for Q stays exact
+    constexpr bool EARLY = G::NS == 2;      // two-slot ring: tile 1 is requested in the prologue together with tile 0 (both slots are free then), not behind tile 0's barrier (+1 %)
+    if (EARLY) issue(1, 1);
 
     // ---- fragment addresses (byte offsets inside a slot)
     // K row `key`, logical 16-byte slot 2 ks + hi, physical slot ^ swz_k(key): one lane base, the step as an XOR at the point of use
@@ -349,13 +351,13 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
         if (j == 1) tr2 = wall_clock64();
 #endif
         // tile j has landed (this wave's pieces: all but the NP * (tiles still in flight behind it) youngest loads), then everybody's
-        if (PD >= 2 && j + 1 < nkt) {
+        if (EARLY ? j == 0 : (PD >= 2 && j + 1 < nkt)) {
             if (G::NP == 4) SA32_VMCNT(4); else SA32_VMCNT(8);
         } else {
             SA32_VMCNT(0);
         }
         if (!(SA32_ABLATE & 2)) SA32_BARRIER();
-        if (j + PD < nkt && !(SA32_ABLATE & 1)) issue(j + PD, islot);
+        if (j + PD < nkt && !(SA32_ABLATE & 1) && !(EARLY && j == 0)) issue(j + PD, islot);
         const uint64_t vnext = vbits[min(j + 1, nkt - 1)];
         const uint32_t vlo = __builtin_amdgcn_readfirstlane((uint32_t)vm), vhi = __builtin_amdgcn_readfirstlane((uint32_t)(vm >> 32));
         if (j <= jlast && (vlo | vhi) != 0u && !(SA32_ABLATE & 8)) {
@@ -369,6 +371,7 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
         islot = (islot + 1 == G::NS) ? 0 : islot + 1;
     }
 
+    if (EARLY) SA32_VMCNT(0);                                           // (one key tile: the early request of "tile 1" must not outlive the workgroup's LDS)
     // ---- epilogue: fold the lane pair's row sums, normalise, store O (16-byte stores after a v_permlane32_swap) and the LSE
 #if SA32_TRACE
     const long long tr3 = wall_clock64();
@@ -504,6 +507,8 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dq_kernel(SA32BwdArgs a) {
     };
 #pragma unroll
     for (int j = 0; j < PD; ++j) issue(j, j);
+    constexpr bool EARLY = NS == 2;
+    if (EARLY) issue(1, 1);
 
     const int lds0 = (int)(unsigned)(size_t)(lds_void*)smem;
     const int rbase = rowfrag_base<D>(lane);
@@ -625,10 +630,10 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dq_kernel(SA32BwdArgs a) {
     uint64_t vm = vbits[0];
     int slot = 0, islot = PD % NS;
     for (int j = 0; j < nkt; ++j) {
-        if (PD >= 2 && j + 1 < nkt) { if (G::NP == 4) SA32_VMCNT(4); else SA32_VMCNT(8); }       // tile j landed, tile j + 1 may be in flight
+        if (EARLY ? j == 0 : (PD >= 2 && j + 1 < nkt)) { if (G::NP == 4) SA32_VMCNT(4); else SA32_VMCNT(8); }       // tile j landed, tile j + 1 may be in flight
         else SA32_VMCNT(0);
         SA32_BARRIER();
-        if (j + PD < nkt) issue(j + PD, islot);
+        if (j + PD < nkt && !(EARLY && j == 0)) issue(j + PD, islot);
         const uint64_t vnext = vbits[min(j + 1, nkt - 1)];
         const uint32_t vlo = __builtin_amdgcn_readfirstlane((uint32_t)vm), vhi = __builtin_amdgcn_readfirstlane((uint32_t)(vm >> 32));
         if (j <= jlast && (vlo | vhi) != 0u) body(j, vlo, vhi, (vlo & vhi) != 0xffffffffu, slot);
@@ -637,6 +642,7 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dq_kernel(SA32BwdArgs a) {
         islot = (islot + 1 == NS) ? 0 : islot + 1;
     }
 
+    if (EARLY) SA32_VMCNT(0);
     const uint32_t orow = wave_active ? (uint32_t)trow * ldgB : OOB;
 #pragma unroll
     for (int db = 0; db < G::NDB; ++db)
@@ -733,6 +739,8 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
     };
 #pragma unroll
     for (int t = 0; t < PD; ++t) issue(i0 + t, t);                      // (a tile past the last query row reads as zeros)
+    constexpr bool EARLY = NS == 2;
+    if (EARLY) issue(i0 + 1, 1);
 
     const int lds0 = (int)(unsigned)(size_t)(lds_void*)smem;
     const int rbase = rowfrag_base<D>(lane);
@@ -842,16 +850,17 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
 
     int slot = 0, islot = PD % NS;
     for (int i = i0; i < nqt; ++i) {
-        if (PD >= 2 && i + 1 < nqt) { if (GB::NPB == 6) SA32_VMCNT(6); else SA32_VMCNT(10); }     // tile i landed, tile i + 1 may be in flight
+        if (EARLY ? i == i0 : (PD >= 2 && i + 1 < nqt)) { if (GB::NPB == 6) SA32_VMCNT(6); else SA32_VMCNT(10); }     // tile i landed, tile i + 1 may be in flight
         else SA32_VMCNT(0);
         SA32_BARRIER();
-        if (i + PD < nqt) issue(i + PD, islot);
+        if (i + PD < nqt && !(EARLY && i == i0)) issue(i + PD, islot);
         // this wave's keys are seen by some row of the tile iff its first key k0 <= last row + P
         if (wave_has_keys && k0 <= i * 64 + 63 + a.P) body(i, slot);
         slot = (slot + 1 == NS) ? 0 : slot + 1;
         islot = (islot + 1 == NS) ? 0 : islot + 1;
     }
 
+    if (EARLY) SA32_VMCNT(0);
     // ---- epilogue: dK = -acc, dV rows (lane = key row: the forward kernel's output store)
     const uint32_t orow = (krow < Tk) ? (uint32_t)krow * ldgB : OOB;
 #pragma unroll
