@@ -189,6 +189,25 @@ class MPTAttention(nn.Module):
             self.__dict__["_qkv_cache"] = cache
         return cache[1]
 
+    def _lora_qkv(self):
+        """The fused frozen [3d, d] weight / [3d] bias under LoRA adapters on q_proj and v_proj (peft's OPT targets) with a plain
+        frozen k_proj, else None.  Same derived-copy cache as _frozen_qkv."""
+        q, k, v = self.q_proj, self.k_proj, self.v_proj
+        if not (hasattr(q, "lora_A") and hasattr(v, "lora_A") and type(k) is nn.Linear) or q.r != v.r or q.scaling != v.scaling:
+            return None
+        ps = (q.base_layer.weight, k.weight, v.base_layer.weight, q.base_layer.bias, k.bias, v.base_layer.bias)
+        if any(p is None or p.requires_grad for p in ps):
+            return None
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
+        cache = self.__dict__.get("_lora_qkv_cache")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                w = torch.cat([ps[0].float() * self.scaling, ps[1].float(), ps[2].float()], 0).to(ps[0].dtype).contiguous()
+                b = torch.cat([ps[3].float() * self.scaling, ps[4].float(), ps[5].float()], 0).to(ps[0].dtype).contiguous()
+            cache = (key, (w, b))
+            self.__dict__["_lora_qkv_cache"] = cache
+        return cache[1]
+
     # -- causal self-attention of the (frozen) OPT layers: HIP flash kernels, no [B,1,T,T] mask, no [B,H,T,T] scores
     def _forward_self(self, hidden_states, attention_mask, layer_head_mask, output_attentions, past_key_value=None):
         H = self.num_heads
@@ -215,6 +234,11 @@ class MPTAttention(nn.Module):
             o = ops.selfattn_core_prefix(q, k, v, attention_mask, H, P)
         elif fused is not None:              # frozen layer: one QKV GEMM forward, one dgrad GEMM backward, no gradient adds
             o = ops.selfattn_core_fused(ops.frozen_linear(hidden_states, *fused), attention_mask, H)
+        elif (lq := self._lora_qkv()) is not None and ops.lora_qkv_supported(hidden_states, lq[0], self.q_proj.r):
+            # LoRA on q_proj / v_proj: one node for the three projections (fused base GEMM, one dgrad GEMM, no gradient adds)
+            qkv = ops.lora_qkv(hidden_states, lq[0], lq[1], self.q_proj.lora_A, self.q_proj.lora_B, self.v_proj.lora_A, self.v_proj.lora_B,
+                               self.q_proj.scaling, self.scaling)
+            o = ops.selfattn_core_fused(qkv, attention_mask, H)
         else:
             if type(self.q_proj) is nn.Linear and self.q_proj.weight.requires_grad:
                 q = ops.linear(hidden_states, self.q_proj.weight, self.q_proj.bias, out_scale=self.scaling)

@@ -333,6 +333,39 @@ def test_lora_linear(dtype, M, N, K):
     assert_close(Bd.grad.float(), Br.grad, t, "dB")
 
 
+def test_lora_qkv_fused_node_vs_fp32_definition():
+    """q | k | v of a layer with LoRA on q_proj and v_proj as one node (ops.lora_qkv: fused base GEMM, low-rank updates accumulated in
+    place, one dgrad GEMM) against the fp32 torch definition of the three projections, config-4 layer dims, 8192 rows."""
+    from mmgl_amd import ops
+    B, T, d, r, s, qs = 8, 1024, 2048, 16, 2.0, 0.125
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, T, d, generator=g)
+    Ws = [torch.randn(d, d, generator=g) * d ** -0.5 for _ in range(3)]
+    bs = [torch.randn(d, generator=g) * 0.1 for _ in range(3)]
+    Aq, Av = (torch.randn(r, d, generator=g) * d ** -0.5 for _ in range(2))
+    Bq, Bv = (torch.randn(d, r, generator=g) * 0.3 for _ in range(2))
+    wgt = torch.randn(B, T, 3 * d, generator=g) * (200.0 / (B * T)) ** 0.5
+    dt = torch.bfloat16
+    xd, Aqd, Bqd, Avd, Bvd = (dev(t_, dt) for t_ in (x, Aq, Bq, Av, Bv))
+    Wd = [w_.to(dt).cuda() for w_ in Ws]
+    bd = [b_.to(dt).cuda() for b_ in bs]
+    w_qkv = torch.cat([Wd[0].float() * qs, Wd[1].float(), Wd[2].float()], 0).to(dt).contiguous()
+    b_qkv = torch.cat([bd[0].float() * qs, bd[1].float(), bd[2].float()], 0).to(dt).contiguous()
+    assert ops.lora_qkv_supported(xd, w_qkv, r)
+    qkv = ops.lora_qkv(xd, w_qkv, b_qkv, Aqd, Bqd, Avd, Bvd, s, qs)
+    (qkv * wgt.to(dt).cuda()).sum().backward()
+    xr, Aqr, Bqr, Avr, Bvr = (t_.detach().float().requires_grad_() for t_ in (xd, Aqd, Bqd, Avd, Bvd))
+    q = (F.linear(xr, Wd[0].float(), bd[0].float()) + s * (xr @ Aqr.t()) @ Bqr.t()) * qs
+    k = F.linear(xr, Wd[1].float(), bd[1].float())
+    v = F.linear(xr, Wd[2].float(), bd[2].float()) + s * (xr @ Avr.t()) @ Bvr.t()
+    ref = torch.cat([q, k, v], -1)
+    (ref * wgt.to(dt).float().cuda()).sum().backward()
+    assert_close(qkv.float(), ref, 3e-2, "qkv")
+    assert_close(xd.grad.float(), xr.grad, 3e-2, "dx")
+    for name, a_, b_ in (("dAq", Aqd, Aqr), ("dBq", Bqd, Bqr), ("dAv", Avd, Avr), ("dBv", Bvd, Bvr)):
+        assert_close(a_.grad.float(), b_.grad, 3e-2, name)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_neighbor_interleave_vs_oracle(dtype):
     from mmgl_amd import ops
