@@ -122,6 +122,16 @@ int mmgl_rmsnorm_bwd(const void* dy, const void* x, const void* gamma, const flo
                      void* dx, float* dgamma, void* workspace, size_t workspace_bytes,
                      int rows, int cols, int dtype, void* stream);
 
+/* The residual add of a Llama layer fused with the RMSNorm that follows it (transformers' LlamaDecoderLayer: "hidden = residual +
+ * hidden" then the next layer's input_layernorm / this layer's post_attention_layernorm; the OPT counterpart is
+ * mmgl_add_layernorm_fwd/bwd):  sum_out = res + x,  y = RMSNorm(sum_out).  Backward: dres = RMSNorm'(dy) + dsum (dsum = the gradient
+ * arriving on the residual stream, may be NULL) -- also the gradient of x.  dgamma fp32 optional (workspace as mmgl_rmsnorm_bwd). */
+int mmgl_add_rmsnorm_fwd(const void* x, const void* res, const void* gamma, void* sum_out, void* y, float* rstd,
+                         int rows, int cols, float eps, int dtype, void* stream);
+int mmgl_add_rmsnorm_bwd(const void* dy, const void* dsum, const void* sum, const void* gamma, const float* rstd,
+                         void* dres, float* dgamma, void* workspace, size_t workspace_bytes,
+                         int rows, int cols, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Gated residual:  y = residual + tanh(gate) * dropout(x, p)
  * replaces: nn.functional.dropout + "residual + tanh(gating) * h", modelling_cross_attention.py:332-335, 356-359
@@ -293,10 +303,14 @@ int mmgl_gemm_nt_masked(const void* x, int ldx, const void* W, int ldw, const vo
  * mmgl_rope_inplace: rotary embedding of the first `nblk` column blocks (H heads x D each: q, then k) of buf [rows, ld], row r
  *   at position r % T; cos_sin [T, D/2, 2] fp32 (cos, sin); rotate_half convention; backward != 0 applies the transpose
  *   rotation (the gradient of the forward one).  In place.
+ * mmgl_rope: the same from src into dst (src != dst, same [rows, ld] layout); column blocks nblk .. nall-1 (v of a fused
+ *   q | k | v buffer) are copied unrotated -- the backward of the rotation without touching the gradient buffer autograd owns.
  * mmgl_swiglu_fwd: y[M,F] = silu(gate_up[:, :F]) * gate_up[:, F:]   (gate_up = one fused [gate | up] GEMM output [M, 2F]).
  * mmgl_swiglu_bwd: dgate_up[M,2F] from dy[M,F] and the saved gate_up. */
 int mmgl_rope_inplace(void* buf, const float* cos_sin, size_t rows, int T, int H, int D, int ld, int nblk, int backward,
                       int dtype, void* stream);
+int mmgl_rope(const void* src, void* dst, const float* cos_sin, size_t rows, int T, int H, int D, int ld, int nblk, int nall,
+              int backward, int dtype, void* stream);
 int mmgl_swiglu_fwd(const void* gate_up, void* y, size_t M, int F, int dtype, void* stream);
 int mmgl_swiglu_bwd(const void* dy, const void* gate_up, void* dgate_up, size_t M, int F, int dtype, void* stream);
 

@@ -36,6 +36,8 @@ SIGNATURES = {
     "mmgl_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, I, P]),
     "mmgl_rmsnorm_fwd": (I, [P, P, P, P, I, I, F, I, P]),
     "mmgl_rmsnorm_bwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, P]),
+    "mmgl_add_rmsnorm_fwd": (I, [P, P, P, P, P, P, I, I, F, I, P]),
+    "mmgl_add_rmsnorm_bwd": (I, [P, P, P, P, P, P, P, P, Z, I, I, I, P]),
     "mmgl_gated_residual_fwd": (I, [P, P, P, P, Z, F, U, I, P]),
     "mmgl_gated_residual_bwd_workspace": (Z, [Z]),
     "mmgl_gated_residual_bwd": (I, [P, P, P, P, P, P, Z, Z, F, U, I, P]),
@@ -69,6 +71,7 @@ SIGNATURES = {
     "mmgl_relu_bwd": (I, [P, P, P, Z, I, P]),
     "mmgl_gemm_set_tile_counter": (I, [P]),
     "mmgl_rope_inplace": (I, [P, P, Z, I, I, I, I, I, I, I, P]),
+    "mmgl_rope": (I, [P, P, P, Z, I, I, I, I, I, I, I, I, P]),
     "mmgl_swiglu_fwd": (I, [P, P, Z, I, I, P]),
     "mmgl_swiglu_bwd": (I, [P, P, P, Z, I, I, P]),
 }

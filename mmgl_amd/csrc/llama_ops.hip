@@ -17,30 +17,35 @@ inline int llama_blocks(size_t nvec) {
 // angle of position t = row % T:  cs [T, D/2] float2 (cos, sin).  sign = +1 forward, -1 backward (the transpose rotation).
 // One thread = 8 consecutive i of one (row, block, head): two 16-byte loads, two 16-byte stores.
 template <typename T>
-__global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ buf, const f32x2* __restrict__ cs, size_t rows, int Tlen, int H, int D,
-                                                   int ld, int nblk, float sign) {
+__global__ __launch_bounds__(256) void rope_kernel(const T* src, T* dst, const f32x2* __restrict__ cs, size_t rows, int Tlen, int H, int D,
+                                                   int ld, int nblk, int nall, float sign) {
+    // src == dst: in place.  Blocks nblk .. nall-1 of a row (v of a fused q | k | v buffer) are copied unrotated (out-of-place calls).
     constexpr int VN = 16 / sizeof(T);
     typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
     const int half = D / 2, per_head = half / VN;
-    const size_t per_row = (size_t)nblk * H * per_head, total = rows * per_row;
+    const size_t per_row = (size_t)nall * H * per_head, total = rows * per_row;
     for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
         const size_t row = id / per_row;
         const int rem = (int)(id - row * per_row);
         const int bh = rem / per_head, c = rem - bh * per_head;          // bh = block * H + head
         const int t = (int)(row % (size_t)Tlen);
-        T* p = buf + row * (size_t)ld + (size_t)bh * D + c * VN;
-        V lo = *(V*)p, hi = *(V*)(p + half);
-        const f32x2* a = cs + (size_t)t * half + c * VN;
-        V olo, ohi;
+        const size_t off = row * (size_t)ld + (size_t)bh * D + c * VN;
+        V lo = *(const V*)(src + off), hi = *(const V*)(src + off + half);
+        if (bh < nblk * H) {
+            const f32x2* a = cs + (size_t)t * half + c * VN;
+            V olo, ohi;
 #pragma unroll
-        for (int e = 0; e < VN; ++e) {
-            const float co = a[e][0], si = a[e][1] * sign;
-            const float x0 = (float)lo[e], x1 = (float)hi[e];
-            olo[e] = (T)(x0 * co - x1 * si);
-            ohi[e] = (T)(x1 * co + x0 * si);
+            for (int e = 0; e < VN; ++e) {
+                const float co = a[e][0], si = a[e][1] * sign;
+                const float x0 = (float)lo[e], x1 = (float)hi[e];
+                olo[e] = (T)(x0 * co - x1 * si);
+                ohi[e] = (T)(x1 * co + x0 * si);
+            }
+            lo = olo;
+            hi = ohi;
         }
-        *(V*)p = olo;
-        *(V*)(p + half) = ohi;
+        *(V*)(dst + off) = lo;
+        *(V*)(dst + off + half) = hi;
     }
 }
 
@@ -95,23 +100,34 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ d
 
 }  // namespace
 
-extern "C" int mmgl_rope_inplace(void* buf, const float* cos_sin, size_t rows, int T, int H, int D, int ld, int nblk, int backward,
-                                 int dtype, void* stream) {
-    MMGL_CHECK_ARG(buf && cos_sin, "mmgl_rope_inplace: null pointer");
-    MMGL_CHECK_ARG(T > 0 && H > 0 && nblk > 0 && ld >= nblk * H * D, "mmgl_rope_inplace: bad sizes (T=%d H=%d D=%d ld=%d nblk=%d)", T, H, D, ld, nblk);
+static int rope_launch(const char* who, const void* src, void* dst, const float* cos_sin, size_t rows, int T, int H, int D, int ld, int nblk,
+                       int nall, int backward, int dtype, void* stream) {
+    MMGL_CHECK_ARG(src && dst && cos_sin, "%s: null pointer", who);
+    MMGL_CHECK_ARG(T > 0 && H > 0 && nblk > 0 && nall >= nblk && ld >= nall * H * D, "%s: bad sizes (T=%d H=%d D=%d ld=%d blocks %d of %d)", who, T, H, D, ld, nblk, nall);
     const int vn = dtype == MMGL_BF16 ? 8 : 4;
-    if (D % (2 * vn) || ld % vn) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "mmgl_rope_inplace: head_dim %d / row stride %d must be multiples of %d", D, ld, 2 * vn);
+    if (D % (2 * vn) || ld % vn) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "%s: head_dim %d / row stride %d must be multiples of %d", who, D, ld, 2 * vn);
     if (rows == 0) return MMGL_OK;
     hipStream_t st = (hipStream_t)stream;
-    const size_t total = rows * (size_t)nblk * H * (D / 2 / vn);
+    const size_t total = rows * (size_t)nall * H * (D / 2 / vn);
     const float sign = backward ? -1.f : 1.f;
     if (dtype == MMGL_BF16)
-        hipLaunchKernelGGL(rope_kernel<bf16>, dim3(llama_blocks(total)), dim3(256), 0, st, (bf16*)buf, (const f32x2*)cos_sin, rows, T, H, D, ld, nblk, sign);
+        hipLaunchKernelGGL(rope_kernel<bf16>, dim3(llama_blocks(total)), dim3(256), 0, st, (const bf16*)src, (bf16*)dst, (const f32x2*)cos_sin, rows, T, H, D, ld, nblk, nall, sign);
     else if (dtype == MMGL_F32)
-        hipLaunchKernelGGL(rope_kernel<float>, dim3(llama_blocks(total)), dim3(256), 0, st, (float*)buf, (const f32x2*)cos_sin, rows, T, H, D, ld, nblk, sign);
-    else MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_rope_inplace: bad dtype %d", dtype);
-    MMGL_CHECK_LAUNCH("mmgl_rope_inplace");
+        hipLaunchKernelGGL(rope_kernel<float>, dim3(llama_blocks(total)), dim3(256), 0, st, (const float*)src, (float*)dst, (const f32x2*)cos_sin, rows, T, H, D, ld, nblk, nall, sign);
+    else MMGL_FAIL(MMGL_ERR_INVALID, "%s: bad dtype %d", who, dtype);
+    MMGL_CHECK_LAUNCH(who);
     return MMGL_OK;
+}
+
+extern "C" int mmgl_rope_inplace(void* buf, const float* cos_sin, size_t rows, int T, int H, int D, int ld, int nblk, int backward,
+                                 int dtype, void* stream) {
+    return rope_launch("mmgl_rope_inplace", buf, buf, cos_sin, rows, T, H, D, ld, nblk, nblk, backward, dtype, stream);
+}
+
+extern "C" int mmgl_rope(const void* src, void* dst, const float* cos_sin, size_t rows, int T, int H, int D, int ld, int nblk, int nall,
+                         int backward, int dtype, void* stream) {
+    MMGL_CHECK_ARG(src != dst, "mmgl_rope: src == dst (use mmgl_rope_inplace)");
+    return rope_launch("mmgl_rope", src, dst, cos_sin, rows, T, H, D, ld, nblk, nall, backward, dtype, stream);
 }
 
 extern "C" int mmgl_swiglu_fwd(const void* gate_up, void* y, size_t M, int F, int dtype, void* stream) {

@@ -388,6 +388,26 @@ extern "C" int mmgl_rmsnorm_fwd(const void* x, const void* gamma, void* y, float
     MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_rmsnorm_fwd: bad dtype %d", dtype);
 }
 
+extern "C" int mmgl_add_rmsnorm_fwd(const void* x, const void* res, const void* gamma, void* sum_out, void* y, float* rstd, int rows,
+                                    int cols, float eps, int dtype, void* stream) {
+    MMGL_CHECK_ARG(x && res && sum_out && y && rstd, "mmgl_add_rmsnorm_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMGL_BF16) return norm_fwd<bf16, true>("mmgl_add_rmsnorm_fwd", x, res, gamma, nullptr, sum_out, y, nullptr, rstd, rows, cols, eps, st);
+    if (dtype == MMGL_F32) return norm_fwd<float, true>("mmgl_add_rmsnorm_fwd", x, res, gamma, nullptr, sum_out, y, nullptr, rstd, rows, cols, eps, st);
+    MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_add_rmsnorm_fwd: bad dtype %d", dtype);
+}
+
+extern "C" int mmgl_add_rmsnorm_bwd(const void* dy, const void* dsum, const void* sum, const void* gamma, const float* rstd, void* dres,
+                                    float* dgamma, void* workspace, size_t workspace_bytes, int rows, int cols, int dtype, void* stream) {
+    MMGL_CHECK_ARG(dy && sum && rstd && dres, "mmgl_add_rmsnorm_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMGL_BF16)
+        return norm_bwd<bf16, true>("mmgl_add_rmsnorm_bwd", dy, sum, gamma, nullptr, rstd, dsum, dres, dgamma, nullptr, workspace, workspace_bytes, rows, cols, st);
+    if (dtype == MMGL_F32)
+        return norm_bwd<float, true>("mmgl_add_rmsnorm_bwd", dy, sum, gamma, nullptr, rstd, dsum, dres, dgamma, nullptr, workspace, workspace_bytes, rows, cols, st);
+    MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_add_rmsnorm_bwd: bad dtype %d", dtype);
+}
+
 extern "C" int mmgl_rmsnorm_bwd(const void* dy, const void* x, const void* gamma, const float* rstd, void* dx,
                                 float* dgamma, void* workspace, size_t workspace_bytes, int rows, int cols, int dtype,
                                 void* stream) {

@@ -44,8 +44,10 @@ class LlamaGatedCrossAttentionLayer(nn.Module):
         a = ops.linear(ops.xattn_core(q, k, v, key_valid, self.num_heads), self.o_proj.weight, None)
         h = ops.gated_residual(h, a, self.gating1, self.dropout, self.training)
         x = ops.rms_norm(h, self.post_attention_layernorm, self.eps)
-        # gate and up are separate trainable parameters (state-dict names of LlamaMLP); their product runs on the SwiGLU kernel
-        gu = torch.cat([ops.linear(x, self.gate_proj.weight, None), ops.linear(x, self.up_proj.weight, None)], dim=-1)
+        # gate and up are separate trainable parameters (state-dict names of LlamaMLP): their WEIGHTS are concatenated per call (180 MB
+        # at 7B dims) so that one GEMM writes the [gate | up] buffer the SwiGLU kernel reads and one dgrad / one wgrad GEMM run backward --
+        # concatenating the two activations cost 1.5 GB of traffic per layer and a contiguous copy of each gradient half
+        gu = ops.linear(x, torch.cat([self.gate_proj.weight, self.up_proj.weight], dim=0), None)
         m = ops.linear(ops.swiglu(gu), self.down_proj.weight, None)
         return ops.gated_residual(h, m, self.gating2, self.dropout, self.training)
 
@@ -71,16 +73,20 @@ class _FrozenLlamaLayer:
             self._cache = (key, qkv, gu)
         return self._cache[1], self._cache[2]
 
-    def __call__(self, h, key_valid, cos_sin):
+    def __call__(self, h, pending, key_valid, cos_sin):
+        """(h, pending) -> (h', pending'): the residual stream and the MLP output NOT yet added to it -- the add runs inside the
+        RMSNorm kernel of whoever consumes the sum next (this layer's successor, the final norm), forward and backward."""
         ly, eps = self.layer, self.cfg.rms_norm_eps
         w_qkv, w_gu = self._fused()
-        x = ops.rms_norm(h, ly.input_layernorm.weight, eps)
+        if pending is None:
+            x = ops.rms_norm(h, ly.input_layernorm.weight, eps)
+        else:
+            h, x = ops.add_rms_norm_pair(pending, h, ly.input_layernorm.weight, eps)
         qkv = ops.rope_qk_(ops.frozen_linear(x, w_qkv, None), cos_sin, self.H)
         a = ops.frozen_linear(ops.selfattn_core_fused(qkv, key_valid, self.H), ly.self_attn.o_proj.weight, None)
-        h = ops.gated_residual(h, a)
-        x = ops.rms_norm(h, ly.post_attention_layernorm.weight, eps)
+        h, x = ops.add_rms_norm_pair(a, h, ly.post_attention_layernorm.weight, eps)
         m = ops.frozen_linear(ops.swiglu(ops.frozen_linear(x, w_gu, None)), ly.mlp.down_proj.weight, None)
-        return ops.gated_residual(h, m)
+        return h, m
 
 
 class LlamaNeighborLM(nn.Module):
@@ -154,13 +160,18 @@ class LlamaNeighborLM(nn.Module):
             ne, valid = neighbor_embeds.to(emb.weight.dtype), valid.to(torch.uint8).contiguous()
         cos_sin = self._cos_sin(T, h.device)
         k = 0
+        pending = None                            # a frozen layer's MLP output, added inside the next RMSNorm kernel
         for l, layer in enumerate(self._frozen):
-            h = layer(h, key_mask, cos_sin)
+            h, pending = layer(h, pending, key_mask, cos_sin)
             if (l + 1) % self.neighbor_layer_wise == 0:
                 if ne is not None:
+                    h, pending = ops.gated_residual(h, pending), None
                     h = self.neighbor_layers[k](h, ne, valid)
                 k += 1
-        hidden = ops.rms_norm(h, self.llama.model.norm.weight, self.config.rms_norm_eps)
+        if pending is None:
+            hidden = ops.rms_norm(h, self.llama.model.norm.weight, self.config.rms_norm_eps)
+        else:
+            hidden = ops.add_rms_norm_pair(pending, h, self.llama.model.norm.weight, self.config.rms_norm_eps)[1]
         nxt = None
         if labels is not None:
             nxt = torch.full_like(labels, -100)

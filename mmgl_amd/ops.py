@@ -360,6 +360,53 @@ def rms_norm(x, gamma, eps=1e-6):
     return _RMSNorm.apply(x, gamma, float(eps))
 
 
+class _AddRMSNorm(torch.autograd.Function):
+    """(s, y) = (res + x, RMSNorm(s)) in one pass (a Llama layer's residual add and the norm that follows it); backward folds the
+    gradient arriving on s into the norm's backward kernel: no residual kernel, no autograd accumulation add."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, eps):
+        require_cuda(x, res)
+        shape = x.shape
+        cols = shape[-1]
+        x2, r2 = x.contiguous().view(-1, cols), res.contiguous().view(-1, cols)
+        rows = x2.shape[0]
+        s, y = torch.empty_like(x2), torch.empty_like(x2)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        g = None if gamma is None else gamma.to(x.dtype).contiguous()
+        _lib.call("mmgl_add_rmsnorm_fwd", dict(bytes=4.0 * rows * cols * x.element_size()), ptr(x2), ptr(r2), ptr(g), ptr(s), ptr(y), ptr(rstd),
+                  rows, cols, eps, dtype_code(x), stream_ptr())
+        ctx.save_for_backward(s, g, rstd)
+        ctx.set_materialize_grads(False)
+        ctx.shape = shape
+        ctx.pgrad = gamma is not None and gamma.requires_grad
+        ctx.pdtype = None if gamma is None else gamma.dtype
+        return s.view(shape), y.view(shape)
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        s, g, rstd = ctx.saved_tensors
+        rows, cols = s.shape
+        if dy is None:                                        # only the residual stream was used downstream
+            return ds, ds, None, None
+        dy2 = dy.contiguous().view(rows, cols)
+        ds2 = None if ds is None else ds.contiguous().view(rows, cols)
+        dres = torch.empty_like(s)
+        dgamma = torch.empty(cols, dtype=torch.float32, device=s.device) if ctx.pgrad else None
+        ws = _ws(lib().mmgl_norm_bwd_workspace(rows, cols) if ctx.pgrad else 0, s.device)
+        _lib.call("mmgl_add_rmsnorm_bwd", dict(bytes=(3.0 + (ds2 is not None)) * rows * cols * s.element_size()), ptr(dy2), ptr(ds2), ptr(s), ptr(g),
+                  ptr(rstd), ptr(dres), ptr(dgamma), ptr(ws), ws.numel(), rows, cols, dtype_code(s), stream_ptr())
+        dres = dres.view(ctx.shape)
+        return dres, dres, (dgamma.to(ctx.pdtype) if dgamma is not None else None), None
+
+
+def add_rms_norm_pair(x, res, gamma, eps=1e-6):
+    """Differentiable (s, RMSNorm(s)) with s = res + x: one forward and one backward kernel for the pair."""
+    if x.shape != res.shape:
+        raise ValueError(f"add_rms_norm_pair: shapes differ {tuple(x.shape)} vs {tuple(res.shape)}")
+    return _AddRMSNorm.apply(x, res, gamma, float(eps))
+
+
 # ------------------------------------------------------------------------------------------ gated residual
 class _GatedResidual(torch.autograd.Function):
     @staticmethod
@@ -1125,11 +1172,12 @@ class _RopeQK(torch.autograd.Function):
     def backward(ctx, dqkv):
         (cos_sin,) = ctx.saved_tensors
         T, H, D = ctx.meta
-        dqkv = dqkv.clone(memory_format=torch.contiguous_format)        # autograd owns the incoming buffer: rotate a copy, never in place
+        dqkv = dqkv.contiguous()                                         # autograd owns the incoming buffer: rotate INTO a new one, never in place
+        out = torch.empty_like(dqkv)
         rows = dqkv.numel() // dqkv.shape[-1]
-        _lib.call("mmgl_rope_inplace", dict(bytes=2.0 * rows * (2 * dqkv.shape[-1] // 3) * dqkv.element_size()), ptr(dqkv), ptr(cos_sin), rows, T, H, D,
-                  dqkv.shape[-1], 2, 1, dtype_code(dqkv), stream_ptr())
-        return dqkv, None, None
+        _lib.call("mmgl_rope", dict(bytes=2.0 * rows * dqkv.shape[-1] * dqkv.element_size()), ptr(dqkv), ptr(out), ptr(cos_sin), rows, T, H, D,
+                  dqkv.shape[-1], 2, 3, 1, dtype_code(dqkv), stream_ptr())
+        return out, None, None
 
 
 def rope_qk_(qkv, cos_sin, num_heads):

@@ -158,6 +158,36 @@ def test_rmsnorm(rows, cols, dtype):
     assert_close(gd.grad.float(), gr.grad, t, "dgamma")
 
 
+@pytest.mark.parametrize("rows,cols", [(33, 128), (512, 4096)])
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("use_sum,gamma_grad", [(True, True), (True, False), (False, False)])
+def test_add_rms_norm_pair(rows, cols, dtype, use_sum, gamma_grad):
+    """(s, y) = (x + r, RMSNorm(x + r)), both outputs feeding the loss: dx = dr = RMSNorm'(dy) + ds from one backward kernel."""
+    from mmgl_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    x, r = torch.randn(rows, cols, generator=g), torch.randn(rows, cols, generator=g) * 2
+    gamma = torch.randn(cols, generator=g) * 0.2 + 1
+    w1, w2 = torch.randn(rows, cols, generator=g), torch.randn(rows, cols, generator=g)
+    xd, rd = dev(x, dtype), dev(r, dtype)
+    gd = dev(gamma, dtype) if gamma_grad else gamma.to(dtype).cuda()
+    s, y = ops.add_rms_norm_pair(xd, rd, gd, 1e-6)
+    loss = (y * w1.to(dtype).cuda()).sum() + ((s * w2.to(dtype).cuda()).sum() if use_sum else 0)
+    loss.backward()
+    xr, rr, gr = (t_.detach().float().cpu().requires_grad_() for t_ in (xd, rd, gd))
+    sr = xr + rr
+    sr = sr + ((xd + rd).detach().float().cpu() - sr).detach()          # the rounded sum, gradient of the plain sum
+    yr = sr * torch.rsqrt(sr.pow(2).mean(-1, keepdim=True) + 1e-6) * gr
+    lr = (yr * w1.to(dtype).float()).sum() + ((sr * w2.to(dtype).float()).sum() if use_sum else 0)
+    lr.backward()
+    t = tol(dtype)
+    assert torch.equal(s, (xd + rd).detach())
+    assert_close(y.float(), yr, t, "y")
+    assert_close(xd.grad.float(), xr.grad, t, "dx")
+    assert torch.equal(xd.grad, rd.grad)
+    if gamma_grad:
+        assert_close(gd.grad.float(), gr.grad, t, "dgamma")
+
+
 @pytest.mark.parametrize("n", [(3, 7, 64), (4, 640, 2048), (1, 5, 13)])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gated_residual_eval(n, dtype):

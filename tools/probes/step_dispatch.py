@@ -22,8 +22,18 @@ margs = bench.make_args(cfg)
 torch.manual_seed(1234)
 device = torch.device("cuda", 0)
 cls = M.SelfAttentionModel if cfg.get("kind") == "lora" else M.CrossAttentionModel
-with torch.device("cpu"):
-    model = cls(margs, tokenizer=None, lm_config=lm_cfg, text_config=txt_cfg, visual_config=vis_cfg)
+if cfg["kind"] == "llama":
+    torch.set_default_dtype(torch.bfloat16)
+    with torch.device(device):
+        model = cls(margs, tokenizer=None, lm_config=lm_cfg, text_config=txt_cfg, visual_config=vis_cfg)
+    torch.set_default_dtype(torch.float32)
+else:
+    with torch.device("cpu"):
+        model = cls(margs, tokenizer=None, lm_config=lm_cfg, text_config=txt_cfg, visual_config=vis_cfg)
+with torch.no_grad():
+    for n_, p in model.named_parameters():
+        if n_.endswith("gating1") or n_.endswith("gating2"):
+            p.fill_(0.5)
 model = model.to(torch.bfloat16).to(device).train()
 engine = DataParallelEngine(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.01)
 batch, _ = bench.synthetic_batch(B, cfg, seed=1234, device=device)
