@@ -261,6 +261,10 @@ int mmgl_adamw_step(void* param, float* master, const void* grad, float* exp_avg
  * returns 2): both take strided operands and apply the whole epilogue in the kernel.  Anything else (returns 0) is composed from
  * mmgl_linear_fwd + the elementwise kernels.
  * ldx / ldw / ldy: row strides in elements (residual and zmask share ldy); the composed path needs dense operands.
+ * K may exceed ldx by less than 128 when columns ldx.. of W are zero (a contraction length padded to the kernels' K step: the
+ * lm_head dgrad over a 50272-entry vocabulary): the tail of row r of x then reads the head of row r + 1 (nothing is read past
+ * the last row: the buffer descriptor zero-fills).  PRECONDITION of that form: x finite -- 0 * Inf = NaN, so a non-finite element
+ * at the head of row r + 1 would also poison row r of the output.
  * mmgl_relu_bwd: out = dy * (y > 0), the backward of a stand-alone ReLU epilogue (in place allowed). */
 int mmgl_gemm_nt_fast(int M, int N, int K, int ldx, int ldw, int ldy, int dtype);
 /* workspace: shapes with fewer 256x256 output tiles than the chip has CUs and a long contraction (the reference's batch of 4:

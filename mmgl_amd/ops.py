@@ -5,6 +5,7 @@ entry point on torch's current stream and returns fresh tensors owned by autogra
 """
 import math
 import os
+import threading
 import weakref
 
 import torch
@@ -1052,6 +1053,13 @@ def _row_strided(t2, cols, n_out):
     return t2.contiguous()
 
 
+# The ReLU mask bits fc1's forward produced travel from _FrozenLinear.forward to frozen_linear (its caller, a few lines below, which hangs
+# them on the output tensor) through this per-THREAD slot: autograd Functions can only return tensors.  A consumer that does not find
+# the attribute (a wrapper or view dropped it) falls back to the activation as the mask.
+_HANDOVER = threading.local()
+_HANDOVER.relu_bits = None
+
+
 class _FrozenLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, mask_dx, premasked, residual=None, relu_bits=None, relu_pitch=0):
@@ -1072,7 +1080,7 @@ class _FrozenLinear(torch.autograd.Function):
                     # the ReLU mask leaves as bits beside the activation: fc2's backward applies those (16 bytes per lane and
                     # tile) instead of re-reading -- and keeping -- the [M, ffn] activation
                     y, bits = gemm_nt_relu_bits(x2, wc, b, out.reshape(-1, N))
-                    _FrozenLinear._last_bits = (bits, pitch)
+                    _HANDOVER.relu_bits = (bits, pitch)
                 else:
                     y = gemm_nt(x2, wc, b, act=act, out=out.reshape(-1, N))
             else:
@@ -1138,11 +1146,11 @@ def frozen_linear(x, weight, bias, relu=False, mask_dx=False, bwd_premasked=Fals
         raise ValueError("frozen_linear: bwd_premasked needs the ReLU epilogue")
     if residual is not None and (code or residual.shape[:-1] != x.shape[:-1] or residual.shape[-1] != weight.shape[0]):
         raise ValueError("frozen_linear: `residual` ([..., out_features], added in the GEMM epilogue) goes with no activation")
-    _FrozenLinear._last_bits = None
+    _HANDOVER.relu_bits = None
     mb = getattr(x, "_mmgl_relu_bits", None) if mask_dx else None
     y = _FrozenLinear.apply(x, weight, bias, code, bool(mask_dx), bool(bwd_premasked), residual, None if mb is None else mb[0], 0 if mb is None else mb[1])
-    if _FrozenLinear._last_bits is not None:                 # fc1 of a frozen FFN left its ReLU mask as bits: hand them to the consumer
-        y._mmgl_relu_bits, _FrozenLinear._last_bits = _FrozenLinear._last_bits, None
+    if _HANDOVER.relu_bits is not None:                      # fc1 of a frozen FFN left its ReLU mask as bits: hand them to the consumer
+        y._mmgl_relu_bits, _HANDOVER.relu_bits = _HANDOVER.relu_bits, None
     return y
 
 
