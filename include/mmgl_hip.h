@@ -283,9 +283,12 @@ int mmgl_relu_bwd(const void* dy, const void* y, void* out, size_t n, int dtype,
  *   static schedule (tile i * grid + workgroup) a workgroup whose CU is shared with the collective's kernel finishes its tiles
  *   late and the whole GEMM waits for it (+38 % measured); with a counter, workgroups take tiles as they become free.
  *   counter: DEVICE pointer to 16 uint32, all zero, owned by the caller and left all zero by every launch; NULL (the default)
- *   = static schedule.  The setting belongs to the calling host thread (like mmgl_last_error) and applies to its later GEMM
- *   launches; launches that may run concurrently on the device (different streams) must be given different counters. */
+ *   = static schedule.  The setting belongs to the CURRENT DEVICE (hipGetDevice of the caller), process-wide: it also applies to
+ *   launches from other host threads -- autograd runs the backward GEMMs, the ones that overlap the collective, on its own device
+ *   thread.  GEMMs of that device must not run concurrently on two streams while a counter is set (they would share it).
+ *   mmgl_gemm_get_tile_counter: the current device's counter (NULL: static schedule). */
 int mmgl_gemm_set_tile_counter(void* counter);
+void* mmgl_gemm_get_tile_counter(void);
 /* The ReLU mask of a frozen FFN as bits (replaces: keeping relu(fc1(x)) [M, ffn] for autograd's threshold_backward of
  * model/modelling_cross_attention.py:352-355, and re-reading it in fc2's dgrad).
  *   mmgl_gemm_nt_relu_bits: y = relu((x W^T + bias) * out_scale) as mmgl_gemm_nt with act = 1, plus bits_out: one bit per

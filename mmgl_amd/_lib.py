@@ -70,6 +70,7 @@ SIGNATURES = {
     "mmgl_gemm_nt": (I, [P, I, P, I, P, P, P, P, I, I, I, I, I, F, P, Z, I, P]),
     "mmgl_relu_bwd": (I, [P, P, P, Z, I, P]),
     "mmgl_gemm_set_tile_counter": (I, [P]),
+    "mmgl_gemm_get_tile_counter": (P, []),
     "mmgl_rope_inplace": (I, [P, P, Z, I, I, I, I, I, I, I, P]),
     "mmgl_rope": (I, [P, P, P, Z, I, I, I, I, I, I, I, I, P]),
     "mmgl_swiglu_fwd": (I, [P, P, Z, I, I, P]),

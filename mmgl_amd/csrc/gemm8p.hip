@@ -28,6 +28,7 @@
 // Needs K % 128 == 0, K >= 256, N % 16 == 0.  Everything else goes to the 128x128 kernel of gemm.hip.
 #include "common.h"
 #include "gemm8p.h"
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -739,8 +740,17 @@ size_t gemm8p_split_bytes(int M, int N, int K) {
     return sp ? (size_t)(cdiv(M, 256) * cdiv(N, 256) - d) * sp * (256 * 256 * sizeof(float)) : 0;
 }
 
-// the calling thread's tile counters (mmgl_gemm_set_tile_counter); NULL = static tile schedule
-static thread_local unsigned* g_tile_counter = nullptr;
+// Tile counters per DEVICE (mmgl_gemm_set_tile_counter); NULL = static tile schedule.  Process-wide, not per thread: the GEMMs that
+// overlap a collective are the backward ones, and those are launched from autograd's device thread, not from the thread that
+// switched the schedule on (a thread_local pointer left exactly those launches on the static schedule).
+static std::atomic<unsigned*> g_tile_counter[64];
+static std::atomic<int> g_tile_counters_set{0};
+static unsigned* p8_tile_counter() {
+    if (!g_tile_counters_set.load(std::memory_order_relaxed)) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    return g_tile_counter[dev & 63].load(std::memory_order_acquire);
+}
 
 int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, const bf16* resid,
                   const bf16* zmask, int M, int N, int K, int act, float scale, hipStream_t st, float* part, size_t part_bytes,
@@ -784,7 +794,7 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
     a.stagger = 0;
     a.stag_mask = 0;
     a.tile0 = 0;
-    a.sched = g_tile_counter;
+    a.sched = p8_tile_counter();
     if (direct > 0) {
         a.total = direct;
         const int grid = direct < n_cu ? direct : n_cu;
@@ -835,6 +845,12 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
 }
 
 extern "C" int mmgl_gemm_set_tile_counter(void* counter) {
-    g_tile_counter = (unsigned*)counter;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "mmgl_gemm_set_tile_counter: hipGetDevice: %s", hipGetErrorString(e));
+    unsigned* old = g_tile_counter[dev & 63].exchange((unsigned*)counter, std::memory_order_acq_rel);
+    g_tile_counters_set.fetch_add((counter != nullptr) - (old != nullptr), std::memory_order_relaxed);
     return MMGL_OK;
 }
+
+extern "C" void* mmgl_gemm_get_tile_counter(void) { return p8_tile_counter(); }

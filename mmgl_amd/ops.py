@@ -914,15 +914,17 @@ def gemm_dynamic_schedule(enable=True, device=None):
     (mmgl_gemm_set_tile_counter): workgroups take tiles from per-XCD counters as they become free.  The data-parallel engine
     turns it on when it runs with more than one rank: the bucket all-reduces of the backward pass share the CUs with these GEMMs,
     and a statically scheduled GEMM waits for its displaced workgroups (reference DDP overlap: run_generation.py:317-319, 485).
-    One counter block per device; every launch leaves it zeroed, GEMMs of one process run on one stream."""
+    One counter block per device, process-wide (the backward GEMMs are launched from autograd's device thread); every launch leaves it
+    zeroed, GEMMs of one device run on one stream."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    if not enable:
-        lib().mmgl_gemm_set_tile_counter(None)
-        return None
-    c = _tile_counters.get(device)
-    if c is None:
-        c = _tile_counters[device] = torch.zeros(16, dtype=torch.int32, device=device)
-    lib().mmgl_gemm_set_tile_counter(ptr(c))
+    with torch.cuda.device(device):                          # the C side keys the setting by hipGetDevice
+        if not enable:
+            lib().mmgl_gemm_set_tile_counter(None)
+            return None
+        c = _tile_counters.get(device)
+        if c is None:
+            c = _tile_counters[device] = torch.zeros(16, dtype=torch.int32, device=device)
+        lib().mmgl_gemm_set_tile_counter(ptr(c))
     return c
 
 

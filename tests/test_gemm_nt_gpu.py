@@ -255,6 +255,41 @@ def test_dynamic_tile_schedule_is_bitwise_the_static_one(M, N, K, act, bias, res
     assert torch.equal(y0, y1) and torch.equal(y0, y2)
 
 
+def test_dynamic_tile_schedule_reaches_the_backward_thread():
+    """The GEMMs that overlap the gradient all-reduce are the BACKWARD ones, and autograd launches those from its own device thread:
+    the schedule set from the main thread must be what a launch from another thread sees (a thread-local setting left exactly those
+    launches static)."""
+    import threading
+    from mmgl_amd import _lib, ops
+    L = _lib.lib()
+    seen = {}
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            seen["fwd"] = (threading.get_ident(), L.mmgl_gemm_get_tile_counter())
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            seen["bwd"] = (threading.get_ident(), L.mmgl_gemm_get_tile_counter())
+            return g
+
+    assert L.mmgl_gemm_get_tile_counter() is None
+    ctr = ops.gemm_dynamic_schedule(True)
+    try:
+        x = torch.randn(8, device="cuda", requires_grad=True)
+        Probe.apply(x).sum().backward()
+        t = threading.Thread(target=lambda: seen.__setitem__("thread", (threading.get_ident(), L.mmgl_gemm_get_tile_counter())))
+        t.start()
+        t.join()
+    finally:
+        ops.gemm_dynamic_schedule(False)
+    assert seen["bwd"][0] != seen["fwd"][0], "autograd ran backward on the calling thread: the test does not probe what it is meant to"
+    assert seen["fwd"][1] == seen["bwd"][1] == seen["thread"][1] == ctr.data_ptr()
+    assert L.mmgl_gemm_get_tile_counter() is None
+
+
 def test_dynamic_tile_schedule_ffn_relu_bits():
     """The frozen FFN pair under the dynamic schedule: fc1 writes its ReLU mask as bits indexed by the tile's virtual id, fc2's dgrad
     reads them back -- whichever workgroup happened to take the tile."""
