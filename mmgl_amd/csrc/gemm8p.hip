@@ -59,8 +59,6 @@ struct P8Args {
     unsigned* bits_out;    // ACT = 1 kernels: one bit per output element (y > 0), [tile][wave][lane][4 dwords], or NULL
     const unsigned* bits_in;   // ZR kernels: the same bits as the mask of this output (instead of a zmask tensor), or NULL
     int tile0;             // first output tile of this launch (a hybrid launch: full tiles first, the rest as K-split items)
-    int stagger;           // start delay per CU group in units of 256 clocks (0 = none)
-    int stag_mask;         // CU groups - 1 (power of two; group = CU index within its XCD & mask)
     long long* trace;      // timing experiments only (P8_TRACE builds): [8 waves][64] clock stamps of workgroup trace_wg
     int trace_wg;
     unsigned* sched;       // dynamic tile schedule (mmgl_gemm_set_tile_counter): [0..7] per-XCD item counters, [8] finished workgroups;
@@ -121,7 +119,7 @@ __device__ __forceinline__ int p8_lane() {
 #endif
 // Cache policy bits of the output stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  nt + sc1: the output tile is streamed out without
 // staying in the L2 that holds the operand tiles the other workgroups of the XCD are about to read -- 40960x8192x2048 1029 -> 920 us
-// (1336 -> 1494 TF), 6144 columns 754 -> 706, 2048 columns 269 -> 253, the seven shapes of tools/probes/gemm_stagger.py 3494 -> 3299 us;
+// (1336 -> 1494 TF), 6144 columns 754 -> 706, 2048 columns 269 -> 253, the seven shapes of tools/probes/gemm_step_shapes.py 3494 -> 3299 us;
 // in the training step (whose next kernel reads that output) 256.3 -> 259.8 samples/s.  0 / 1 / 16 / 17: no change; 2 / 3: as 18 but
 // 2 % behind on the K = 768 shape.
 #ifndef P8_STORE_AUX
@@ -473,16 +471,10 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     };
     auto epilogue = [&]() __attribute__((always_inline)) { epilogue_q(m0, n0, it, 0, 4); };
 
-    // ---- stagger.  Every CU runs equal tiles in lockstep, so all 256 of them would reach their epilogues together and push
-    // 32 MiB of output at the memory system at once; with one in-order vmcnt per wave the next tile's LDS-DMA waits sit behind
-    // those stores, and the whole chip stalls for the drain (measured: ~9 us per tile, 1332 -> 1617 TF at K = 2048 with the
-    // stores removed).  Four groups of CUs (per XCD) start a quarter of a tile apart instead: a quarter of the CUs store while
-    // the others compute, each burst drains at the full bandwidth, and the offsets persist because every tile takes the same
-    // time.  Costs 3/4 of one tile time once per launch: only worth it over several rounds of tiles.
-    if (a.stagger) {
-        const int grp = (blockIdx.x >> 3) & a.stag_mask;
-        for (int i = 0; i < grp * a.stagger; ++i) __builtin_amdgcn_s_sleep(4);           // 4 x 64 clocks each
-    }
+    // (Start offsets between groups of CUs -- a quarter of a tile apart, so that the groups' output bursts do not collide -- paid for
+    // themselves in round 2 (1047 -> 1021 us at 40960x8192x2048) and stopped doing so with the streamed output stores: re-measured in
+    // round 3 for outputs of >= 10 rounds of tiles, groups inside an XCD 946 -> 950-1029 us, groups of whole XCDs 934 -> 935-948 us
+    // (a gross gain of ~3 % against a tail of 2.5-4.4 %).  Removed.)
 
     // ---- prologue: units -1 .. 5 of the stream  (Wa(0) | Xa(0) Wb(0) Xb(0) Wa(1) | Xa(1) Wb(1))
     stage(3, 7, dWc, 0);
@@ -791,20 +783,11 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
     if (part && part_bytes >= gemm8p_split_bytes(M, N, K)) gemm8p_plan(M, N, K, &direct, &nsplit);
     a.trace = nullptr;
     a.trace_wg = 0;
-    a.stagger = 0;
-    a.stag_mask = 0;
     a.tile0 = 0;
     a.sched = p8_tile_counter();
     if (direct > 0) {
         a.total = direct;
         const int grid = direct < n_cu ? direct : n_cu;
-        // MMGL_GEMM_STAGGER = start offset between CU groups in clocks, MMGL_GEMM_STAGGER_GROUPS = 2 / 4 / 8 / 16 / 32 groups
-        static const int stag_clk = [] { const char* e = getenv("MMGL_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
-        static const int stag_grp = [] { const char* e = getenv("MMGL_GEMM_STAGGER_GROUPS"); const int g = e ? atoi(e) : 4;
-                                         return (g >= 2 && g <= 32 && !(g & (g - 1))) ? g : 4; }();
-        static const int stag_rounds = [] { const char* e = getenv("MMGL_GEMM_STAGGER_ROUNDS"); return e ? atoi(e) : 2; }();
-        a.stagger = (stag_clk > 0 && a.total >= stag_rounds * grid) ? (stag_clk + 128) / 256 : 0;
-        a.stag_mask = stag_grp - 1;
 #if P8_TRACE
         if (const char* e = getenv("MMGL_P8_TRACE")) a.trace = (long long*)strtoull(e, nullptr, 0);
         if (const char* e = getenv("MMGL_P8_TRACE_WG")) a.trace_wg = atoi(e);
@@ -829,8 +812,6 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
         a.total = rest;
         a.nsplit = nsplit;
         a.part = part;
-        a.stagger = 0;
-        a.stag_mask = 0;
         a.trace = nullptr;
         const int items = rest * nsplit, g = items < n_cu ? items : n_cu;
         hipLaunchKernelGGL((gemm8p_kernel<5, false>), dim3(g), dim3(512), P8_LDS_ALLOC, st, a);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Time the default step's GEMM shapes through mmgl_gemm_nt under the current MMGL_GEMM_STAGGER* environment
-(one process per setting: the switches are read once).   python tools/probes/gemm_stagger.py"""
+"""Time the default step's seven GEMM shapes through mmgl_gemm_nt under the current environment / MMGL_LIB_PATH (one process per setting:
+the switches are read once).   python tools/probes/gemm_step_shapes.py"""
 import os
 import sys
 
@@ -14,7 +14,7 @@ SHAPES = [(40960, 2048, 2048, 0, False), (40960, 6144, 2048, 0, False), (40960, 
 
 
 def main():
-    tag = f"stagger={os.environ.get('MMGL_GEMM_STAGGER', '0')} groups={os.environ.get('MMGL_GEMM_STAGGER_GROUPS', '4')} rounds={os.environ.get('MMGL_GEMM_STAGGER_ROUNDS', '2')}"
+    tag = os.environ.get("MMGL_LIB_PATH", "default library")
     tot = 0.0
     out = []
     for M, N, K, act, resid in SHAPES:
