@@ -326,10 +326,7 @@ inline int tune_gemm_mid() {
     static const int v = [] { const char* e = getenv("MMGL_GEMM_MID"); return e ? atoi(e) : 1; }();
     return v;
 }
-inline int tune_gemm_big() {
-    static const int v = [] { const char* e = getenv("MMGL_GEMM_BIG"); return e ? atoi(e) : 1; }();
-    return v;
-}
+inline constexpr int tune_gemm_big() { return 1; }
 
 // out[C,R] = transpose(f(in[R,C])) with f = (* scale) and optional ReLU mask from yact[R,C] (> 0);
 // optional colsum[C] (+)= sum over R of f(in) (fp32 atomics are avoided: one block owns a full column strip).
@@ -389,10 +386,7 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const T* __restrict__ dy
     }
 }
 
-inline bool tune_gemm_glds() {
-    static const bool on = [] { const char* e = getenv("MMGL_GEMM_GLDS"); return !e || atoi(e) != 0; }();
-    return on;
-}
+inline constexpr bool tune_gemm_glds() { return true; }
 
 template <typename T> inline int pad_k(int k) { return (k + GT<T>::VN - 1) / GT<T>::VN * GT<T>::VN; }
 
@@ -1337,8 +1331,7 @@ extern "C" int mmgl_gemm_nt(const void* x, int ldx, const void* W, int ldw, cons
 extern "C" size_t mmgl_gemm_nt_relu_bits_bytes(int M, int N, int K, int ldx, int ldw, int ldy, int dtype) {
     if (dtype != MMGL_BF16 || !tune_gemm_8p() || !gemm8p_supported(M, N, K, ldx, ldw, ldy)) return 0;
     if (cdiv(M, 256) * cdiv(N, 256) < tune_gemm_8p_min_tiles()) return 0;
-    static const int on = [] { const char* e = getenv("MMGL_GEMM_RELU_BITS"); return e ? atoi(e) : 1; }();
-    return on ? gemm8p_bits_bytes(M, N) : 0;
+    return gemm8p_bits_bytes(M, N);
 }
 
 extern "C" int mmgl_gemm_nt_relu_bits(const void* x, int ldx, const void* W, int ldw, const void* bias, void* y, int ldy, void* bits_out,

@@ -979,7 +979,7 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
             if (par == 2 && red > tiles) tiles = red;
             return sizeof(T) * 4 * C::ROWIMG + tiles;
         };
-        static const int use64 = [] { const char* e = getenv("MMGL_SELFATTN_DKV64"); return e ? atoi(e) : 1; }();
+        constexpr int use64 = 1;
         if constexpr (sizeof(T) == 2) {
             if (use64) {
                 constexpr int NSBW = D <= 64 ? 4 : 2;

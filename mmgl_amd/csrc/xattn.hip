@@ -987,14 +987,10 @@ struct BwdPlan { int nsg, nchunk, rows_per_chunk; size_t delta_off, dk_off, dv_o
 
 // keys per dK/dV wave: 64 for the bf16 D <= 64 kernel, 32 for the generic one
 inline bool use_dkv64(int D, size_t esz) {
-    static const int on = [] { const char* e = getenv("MMGL_XATTN_DKV64"); return e ? atoi(e) : 1; }();
-    return on && esz == 2;
+    return esz == 2;
 }
 inline int dkv64_keys(int D) { return D <= 64 ? 64 : 32; }
-inline bool use_fused_bwd() {
-    static const int on = [] { const char* e = getenv("MMGL_XATTN_FUSED_BWD"); return e ? atoi(e) : 1; }();
-    return on != 0;
-}
+inline constexpr bool use_fused_bwd() { return true; }
 
 BwdPlan bwd_plan(int B, int H, int T, int S, int D, size_t esz = 2) {
     BwdPlan p;

@@ -257,7 +257,6 @@ class MPTAttention(nn.Module):
         return self._forward_self(hidden_states, attention_mask, layer_head_mask, output_attentions, past_key_value)
 
 
-_FUSE_ADD_LN = os.environ.get("MMGL_FUSE_ADD_LN", "1") != "0"     # A/B switch for the fused residual + LayerNorm pairs
 
 
 class _Deferred:
@@ -331,7 +330,6 @@ class MPTDecoderLayer(nn.Module):
         left to the next layer's first LayerNorm (`defer_residual`, see _Deferred)."""
         pre = self.do_layer_norm_before
         ln1, ln2 = self.self_attn_layer_norm, self.final_layer_norm
-        fuse = isinstance(h, _Deferred) or _FUSE_ADD_LN
         pair = lambda x, r, ln: ops.add_layer_norm_pair(x, r, ln.weight, ln.bias, ln.eps, self.dropout, self.training)
         if isinstance(h, _Deferred):
             if pre:
@@ -343,16 +341,11 @@ class MPTDecoderLayer(nn.Module):
         residual = h
         a, attn_w, _ = self.self_attn(x, attention_mask=attention_mask, layer_head_mask=layer_head_mask,
                                       output_attentions=output_attentions, past_key_value=past_key_value)
-        if fuse and pre:
+        if pre:
             h, x = pair(a, residual, ln2)
-        elif fuse:
+        else:
             _, h = pair(a, residual, ln1)                                                   # post-LN: h = LN(residual + a)
             x = h
-        else:
-            h = ops.gated_residual(residual, a, None, self.dropout, self.training)
-            if not pre:
-                h = self._ln(ln1, h)
-            x = self._ln(ln2, h) if pre else h
         residual = h
         if self.activation_name == "relu":
             # fc1's ReLU backward rides in the epilogue of fc2's dgrad GEMM (mask_dx): no pass over [M, ffn], nothing kept twice
@@ -362,15 +355,12 @@ class MPTDecoderLayer(nn.Module):
             x = lin(lin(x, self.fc1.weight, self.fc1.bias, bwd_premasked=True, **kw), self.fc2.weight, self.fc2.bias, mask_dx=True)
         else:
             x = _lin(self.fc2, self.activation_fn(_lin(self.fc1, x)))
-        if fuse and pre and defer_residual:
+        if pre and defer_residual:
             return _Deferred(residual, x, self.dropout, self.training), attn_w
-        if fuse and not pre:
+        if not pre:
             _, h = pair(x, residual, ln2)
             return h, attn_w
-        h = ops.gated_residual(residual, x, None, self.dropout, self.training)
-        if not pre:
-            h = self._ln(ln2, h)
-        return h, attn_w
+        return ops.gated_residual(residual, x, None, self.dropout, self.training), attn_w
 
     def forward(self, hidden_states, attention_mask=None, neighbor_embeds=None, neighbor_attention_mask=None,
                 layer_head_mask=None, past_key_value=None, output_attentions=False, use_cache=False, defer_residual=False):
@@ -528,7 +518,7 @@ class MPTDecoder(MPTPreTrainedModel):
             raise ValueError(f"The `head_mask` should be specified for {len(self.layers)} layers, but it is for"
                              f" {head_mask.size()[0]}.")
 
-        defer = not output_hidden_states and _FUSE_ADD_LN
+        defer = not output_hidden_states
         for idx, decoder_layer in enumerate(self.layers):
             if output_hidden_states:
                 all_hidden_states += (hidden_states,)

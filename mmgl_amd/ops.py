@@ -580,7 +580,6 @@ def _wgrad_only(dy2, x2, w_like, scale):
     return dw
 
 
-_LORA_ONE_NODE = os.environ.get("MMGL_LORA_ONE_NODE", "1") != "0"      # A/B switch
 
 
 class _LoraLinearBig(torch.autograd.Function):
@@ -706,7 +705,7 @@ def lora_linear(x, weight, bias, lora_A, lora_B, scale, out_scale=1.0):
         # the rank is zero-padded to 256 (autograd slices the gradients back): every product of the low-rank path -- x A^T,
         # (x A^T) B^T, and in backward dy B, (dy B) A, (dy B)^T x, dy^T (x A^T) -- is then a 256-wide GEMM the large-tile kernels
         # (and their K splits) carry, instead of a 16-wide one on a handful of workgroups
-        if _LORA_ONE_NODE and x.dtype == torch.bfloat16 and K % 8 == 0 and N % 8 == 0:
+        if x.dtype == torch.bfloat16 and K % 8 == 0 and N % 8 == 0:
             return _LoraLinearBig.apply(x, weight, bias, lora_A, lora_B, float(scale), float(out_scale))
         if out_scale != 1.0:
             return lora_linear(x, weight, bias, lora_A, lora_B, scale) * out_scale
@@ -1029,14 +1028,13 @@ def frozen_dgrad(g, weight, zmask=None, out=None, bits=None, out_scale=1.0, resi
     return dx
 
 
-_FFN_PITCH = os.environ.get("MMGL_FFN_PITCH", "1") != "0"      # A/B switch
 
 
 def _ffn_pitch(M, N, K, dtype):
     """Row pitch (elements) for the [M, N] hidden buffer between the two linears of a frozen FFN.  A power-of-two row size
     (8192 bf16 = 16 KiB) costs the persistent GEMM ~3 % at that shape (1049 vs 1015 us, tools/probes/gemm_pitch2.py): the buffer
     and its gradient get 128 extra columns of pitch when all four GEMMs that touch them take strided operands (fast path)."""
-    if dtype != torch.bfloat16 or (N * 2) % 8192 or not _FFN_PITCH:
+    if dtype != torch.bfloat16 or (N * 2) % 8192:
         return N
     P, L = N + 128, lib()
     if L.mmgl_gemm_nt_fast(M, N, K, K, K, P, _lib.BF16) == 1 and L.mmgl_gemm_nt_fast(M, K, N, P, N, K, _lib.BF16) == 1:
