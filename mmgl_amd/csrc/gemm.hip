@@ -901,16 +901,23 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     if (accumulate) t += (float)out[c];
     out[c] = (T)t;
 }
-constexpr int COLSUM_SPLITS = 16;
+constexpr int COLSUM_SPLITS = 64;       // upper bound (scratch sizing); a launch uses colsum_splits(N) of them
+// about 1024 workgroups per launch: 16 splits of the rows left a 2048-column gradient on 256 workgroups, one per CU (57 us for 168 MB)
+inline int colsum_splits(int N, int vn) {
+    const int cb = cdiv(N, 16 * vn);
+    int s = (1024 + cb - 1) / cb;
+    return s < 16 ? 16 : (s > COLSUM_SPLITS ? COLSUM_SPLITS : s);
+}
 
 template <typename T>
 int launch_colsum(const T* dy, const T* y, T* out, float* part, int M, int N, float scale, int accumulate, hipStream_t st) {
     constexpr int VN = GT<T>::VN;
     if (N % VN) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "bias gradient: out_features %d must be a multiple of %d", N, VN);
-    dim3 grid(cdiv(N, 16 * VN), COLSUM_SPLITS);
+    const int splits = colsum_splits(N, VN);
+    dim3 grid(cdiv(N, 16 * VN), splits);
     if (y) hipLaunchKernelGGL((colsum_kernel<T, true>), grid, dim3(256), 0, st, dy, y, part, M, N);
     else hipLaunchKernelGGL((colsum_kernel<T, false>), grid, dim3(256), 0, st, dy, y, part, M, N);
-    hipLaunchKernelGGL(colsum_finish_kernel<T>, dim3(cdiv(N, 256)), dim3(256), 0, st, part, out, N, COLSUM_SPLITS, scale, accumulate);
+    hipLaunchKernelGGL(colsum_finish_kernel<T>, dim3(cdiv(N, 256)), dim3(256), 0, st, part, out, N, splits, scale, accumulate);
     MMGL_CHECK_LAUNCH("colsum");
     return MMGL_OK;
 }
