@@ -331,6 +331,10 @@ int mmgl_add_layernorm_bwd(const void* dy, const void* dsum, const void* sum, co
                            size_t workspace_bytes, int rows, int cols, float p_drop, uint64_t seed, int dtype,
                            void* stream);
 int mmgl_activation_fwd(const void* x, void* y, size_t n, int act, int dtype, void* stream);
+/* y[i] = x[i] * (*scale), product in fp32, scale read from device memory (x == y allowed).  The upstream gradient of a scalar
+ * loss -- `loss / args.grad_accumulation_steps` at reference language_modelling/run_generation.py:483 -- applied to a saved
+ * gradient without a host sync. */
+int mmgl_scale(const void* x, const float* scale, void* y, size_t n, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "mmgl_add_layernorm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, F, F, U, I, P]),
     "mmgl_add_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, F, U, I, P]),
     "mmgl_activation_fwd": (I, [P, P, Z, I, I, P]),
+    "mmgl_scale": (I, [P, P, P, Z, I, P]),
     "mmgl_gemm_nt_fast": (I, [I, I, I, I, I, I, I]),
     "mmgl_gemm_nt_workspace": (Z, [I, I, I, I, I, I, I]),
     "mmgl_gemm_nt_relu_bits_bytes": (Z, [I, I, I, I, I, I, I]),

@@ -55,6 +55,26 @@ __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ x, T* __
         for (size_t i = nvec * VN; i < n; ++i) y[i] = (T)act_apply<ACT>((float)x[i]);
 }
 
+// ------------------------------------------------------------------------------------------ y = x * (*scale)
+// The upstream scalar of a loss node (1 / grad_accumulation_steps, reference language_modelling/run_generation.py:483) applied to a
+// saved gradient in fp32 with the scalar read from DEVICE memory: one pass, no host sync, no bf16 rounding of the scalar.
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(const T* __restrict__ x, const float* __restrict__ scale, T* __restrict__ y, size_t n) {
+    typedef typename Vec<T>::type V;
+    constexpr int VN = Vec<T>::N;
+    const float s = *scale;
+    const size_t nvec = n / VN;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const V xv = ((const V*)x)[i];
+        V o;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) o[j] = (T)((float)xv[j] * s);
+        ((V*)y)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = nvec * VN; i < n; ++i) y[i] = (T)((float)x[i] * s);
+}
+
 // ------------------------------------------------------------------------------------------ gated residual
 // y = res + tanh(g) * keep(i) * x / (1-p)        (reference modelling_cross_attention.py:332-335, 356-359)
 template <typename T>
@@ -486,4 +506,15 @@ extern "C" int mmgl_activation_fwd(const void* x, void* y, size_t n, int act, in
     if (dtype == MMGL_BF16) return act_launch<bf16>(x, y, n, act, st);
     if (dtype == MMGL_F32) return act_launch<float>(x, y, n, act, st);
     MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_activation_fwd: bad dtype %d", dtype);
+}
+
+extern "C" int mmgl_scale(const void* x, const float* scale, void* y, size_t n, int dtype, void* stream) {
+    MMGL_CHECK_ARG(x && y && scale, "mmgl_scale: null pointer");
+    if (n == 0) return MMGL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMGL_BF16) hipLaunchKernelGGL(scale_kernel<bf16>, dim3(stream_blocks(n / 8)), dim3(256), 0, st, (const bf16*)x, scale, (bf16*)y, n);
+    else if (dtype == MMGL_F32) hipLaunchKernelGGL(scale_kernel<float>, dim3(stream_blocks(n / 4)), dim3(256), 0, st, (const float*)x, scale, (float*)y, n);
+    else MMGL_FAIL(MMGL_ERR_INVALID, "mmgl_scale: bad dtype %d", dtype);
+    MMGL_CHECK_LAUNCH("mmgl_scale");
+    return MMGL_OK;
 }

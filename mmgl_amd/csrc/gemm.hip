@@ -895,25 +895,36 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
                                                             float scale, int accumulate) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= N) return;
-    float t = 0.f;
-    for (int s = 0; s < splits; ++s) t += part[(size_t)s * N + c];
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;        // four load streams per column instead of one serial chain of `splits` round trips
+    int s = 0;
+    for (; s + 3 < splits; s += 4) {
+        t0 += part[(size_t)s * N + c];
+        t1 += part[(size_t)(s + 1) * N + c];
+        t2 += part[(size_t)(s + 2) * N + c];
+        t3 += part[(size_t)(s + 3) * N + c];
+    }
+    for (; s < splits; ++s) t0 += part[(size_t)s * N + c];
+    float t = (t0 + t1) + (t2 + t3);
     t *= scale;
     if (accumulate) t += (float)out[c];
     out[c] = (T)t;
 }
 constexpr int COLSUM_SPLITS = 64;       // upper bound (scratch sizing); a launch uses colsum_splits(N) of them
 // about 1024 workgroups per launch: 16 splits of the rows left a 2048-column gradient on 256 workgroups, one per CU (57 us for 168 MB)
-inline int colsum_splits(int N, int vn) {
+inline int colsum_splits(int M, int N, int vn) {
     const int cb = cdiv(N, 16 * vn);
     int s = (1024 + cb - 1) / cb;
-    return s < 16 ? 16 : (s > COLSUM_SPLITS ? COLSUM_SPLITS : s);
+    s = s < 16 ? 16 : (s > COLSUM_SPLITS ? COLSUM_SPLITS : s);
+    const int by_rows = M / 128;                       // at least 8 row trips per workgroup (the reference's batch: M = 2560 -> 20 splits)
+    if (s > by_rows) s = by_rows < 1 ? 1 : by_rows;
+    return s;
 }
 
 template <typename T>
 int launch_colsum(const T* dy, const T* y, T* out, float* part, int M, int N, float scale, int accumulate, hipStream_t st) {
     constexpr int VN = GT<T>::VN;
     if (N % VN) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "bias gradient: out_features %d must be a multiple of %d", N, VN);
-    const int splits = colsum_splits(N, VN);
+    const int splits = colsum_splits(M, N, VN);
     dim3 grid(cdiv(N, 16 * VN), splits);
     if (y) hipLaunchKernelGGL((colsum_kernel<T, true>), grid, dim3(256), 0, st, dy, y, part, M, N);
     else hipLaunchKernelGGL((colsum_kernel<T, false>), grid, dim3(256), 0, st, dy, y, part, M, N);

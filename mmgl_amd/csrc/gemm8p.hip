@@ -89,12 +89,12 @@ template <int ACT> __device__ __forceinline__ float p8_act(float v) {
         // exact-GELU with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): ~14 VALU per value instead
         // of libm's erff -- the epilogue runs beside the partner wave's MFMAs and must stay short
         const float z = fabsf(v) * 0.70710678118654752f;
-        const float t = __frcp_rn(1.f + 0.3275911f * z);
+        const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);     // v_rcp_f32 (1 ulp); __frcp_rn / operator/ expand to the 10-instruction IEEE division
         const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
         const float er = 1.f - poly * __expf(-z * z);
         return 0.5f * v * (1.f + copysignf(er, v));
     }
-    else if constexpr (ACT == 3) return v / (1.f + __expf(-1.702f * v));
+    else if constexpr (ACT == 3) return v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
     else if constexpr (ACT == 4) {
         const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
         return 0.5f * v * (1.f + tanhf(u));

@@ -69,11 +69,11 @@ template <int ACT> __device__ __forceinline__ float mid_act(float v) {
     if constexpr (ACT == 1) return fmaxf(v, 0.f);
     else if constexpr (ACT == 2) {                                       // erf by Abramowitz-Stegun 7.1.26, as the persistent kernel's epilogue (gemm8p.hip)
         const float z = fabsf(v) * 0.70710678118654752f;
-        const float t = __frcp_rn(1.f + 0.3275911f * z);
+        const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
         const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
         return 0.5f * v * (1.f + copysignf(1.f - poly * __expf(-z * z), v));
     }
-    else if constexpr (ACT == 3) return v / (1.f + __expf(-1.702f * v));
+    else if constexpr (ACT == 3) return v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
     else if constexpr (ACT == 4) return 0.5f * v * (1.f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
     else return v;
 }

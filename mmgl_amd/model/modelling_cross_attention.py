@@ -300,17 +300,23 @@ class MPTDecoderLayer(nn.Module):
     def _ln(self, ln, x):
         return ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
 
+    def _ln_fanout(self, ln, x):
+        """(residual, LayerNorm(x)): ops.layer_norm_fanout when gradients flow (its backward adds the residual stream's gradient
+        in the LayerNorm kernel), the plain kernel otherwise."""
+        if torch.is_grad_enabled() and x.requires_grad:
+            return ops.layer_norm_fanout(x, ln.weight, ln.bias, ln.eps)
+        return x, ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+
     def _forward_cross(self, h, neighbor_embeds, neighbor_attention_mask, layer_head_mask, output_attentions):
         gated = self.peft_type == "flamingo"
-        residual = h
-        x = self._ln(self.self_attn_layer_norm, h) if self.do_layer_norm_before else h
+        # pre-LN: the block input feeds the LayerNorm AND the residual add -- both gradients meet inside the LayerNorm backward kernel
+        residual, x = self._ln_fanout(self.self_attn_layer_norm, h) if self.do_layer_norm_before else (h, h)
         a, attn_w, _ = self.self_attn(x, neighbor_embeds=neighbor_embeds, neighbor_attention_mask=neighbor_attention_mask,
                                       layer_head_mask=layer_head_mask, output_attentions=output_attentions)
         h = ops.gated_residual(residual, a, self.gating1 if gated else None, self.dropout, self.training)
         if not self.do_layer_norm_before:
             h = self._ln(self.self_attn_layer_norm, h)
-        residual = h
-        x = self._ln(self.final_layer_norm, h) if self.do_layer_norm_before else h
+        residual, x = self._ln_fanout(self.final_layer_norm, h) if self.do_layer_norm_before else (h, h)
         if self.activation_name == "relu":
             # fc1's ReLU backward rides in the epilogue of fc2's dgrad GEMM (mask_dx) instead of a separate pass over [M, ffn]
             x = ops.linear(x, self.fc1.weight, self.fc1.bias, act="relu", bwd_premasked=True)
@@ -336,8 +342,10 @@ class MPTDecoderLayer(nn.Module):
                 h, x = ops.add_layer_norm_pair(h.branch, h.residual, ln1.weight, ln1.bias, ln1.eps, h.p_drop, h.training)
             else:
                 h = x = _materialize(h)
+        elif pre:
+            h, x = self._ln_fanout(ln1, h)
         else:
-            x = self._ln(ln1, h) if pre else h
+            x = h
         residual = h
         a, attn_w, _ = self.self_attn(x, attention_mask=attention_mask, layer_head_mask=layer_head_mask,
                                       output_attentions=output_attentions, past_key_value=past_key_value)

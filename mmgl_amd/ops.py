@@ -256,6 +256,61 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     return _LayerNorm.apply(x, gamma, beta, float(eps))
 
 
+class _LayerNormFanout(torch.autograd.Function):
+    """(x, LayerNorm(x)) for a pre-LN block whose input also feeds the block's residual add (reference :316-320 `residual =
+    hidden_states; hidden_states = self.self_attn_layer_norm(hidden_states)`, :347-350): the gradient arriving on the residual
+    stream is added INSIDE the LayerNorm backward kernel (mmgl_add_layernorm_bwd with the sum = x), instead of autograd's
+    accumulation add over [B, T, d] at every fan-out (10 per step at config 3)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        require_cuda(x)
+        shape = x.shape
+        cols = shape[-1]
+        x2 = x.contiguous().view(-1, cols)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        g = None if gamma is None else gamma.to(x.dtype).contiguous()
+        b = None if beta is None else beta.to(x.dtype).contiguous()
+        _lib.call("mmgl_layernorm_fwd", dict(bytes=2.0 * rows * cols * x.element_size()), ptr(x2), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps,
+                  dtype_code(x), stream_ptr())
+        ctx.save_for_backward(x2, g, mean, rstd)
+        ctx.set_materialize_grads(False)
+        ctx.shape = shape
+        ctx.pgrad = (gamma is not None and gamma.requires_grad, beta is not None and beta.requires_grad)
+        ctx.pdtype = None if gamma is None else gamma.dtype
+        return x, y.view(shape)          # x comes back as an alias of the input (autograd wraps it as a view)
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x2, g, mean, rstd = ctx.saved_tensors
+        rows, cols = x2.shape
+        if dy is None:
+            return dres, None, None, None
+        dy2 = dy.contiguous().view(rows, cols)
+        dr2 = None if dres is None else dres.contiguous().view(rows, cols)
+        dx = torch.empty_like(x2)
+        want = any(ctx.pgrad)
+        dgamma = torch.empty(cols, dtype=torch.float32, device=x2.device) if want else None
+        dbeta = torch.empty(cols, dtype=torch.float32, device=x2.device) if want else None
+        nbytes = lib().mmgl_norm_bwd_workspace(rows, cols) if want else 0
+        ws = _ws(nbytes, x2.device)
+        nt = 3.0 + (dr2 is not None)
+        _lib.call("mmgl_add_layernorm_bwd", dict(bytes=nt * rows * cols * x2.element_size()), ptr(dy2), ptr(dr2), ptr(x2), ptr(g), ptr(mean),
+                  ptr(rstd), ptr(dx), None, ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), rows, cols, 0.0, 0, dtype_code(x2), stream_ptr())
+        dg = dgamma.to(ctx.pdtype) if ctx.pgrad[0] else None
+        db = dbeta.to(ctx.pdtype) if ctx.pgrad[1] else None
+        return dx.view(ctx.shape), dg, db, None
+
+
+def layer_norm_fanout(x, gamma, beta, eps=1e-5):
+    """(residual, LayerNorm(x)) with residual == x: use BOTH outputs downstream (the residual add and the normed branch) so that
+    the two gradients meet inside the LayerNorm backward kernel."""
+    return _LayerNormFanout.apply(x, gamma, beta, float(eps))
+
+
 class _AddLayerNorm(torch.autograd.Function):
     """(s, y) = (res + dropout(x), LayerNorm(s)) in one pass; backward folds the gradient arriving on s into the LayerNorm
     backward kernel, which writes the gradient of res and (when dropout is active) of x -- no separate residual kernels,
@@ -841,8 +896,13 @@ class _LMHeadCrossEntropy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         (dh,) = ctx.saved_tensors
-        # scale in fp32: 1 / grad_accumulation_steps rounded to bf16 first would bias every hidden gradient by up to 0.4 %
-        return (dh.float() * dloss.float()).to(dh.dtype).view(ctx.shape), None, None, None, None
+        # scale in fp32 by the device scalar (mmgl_scale: one pass, no host sync): 1 / grad_accumulation_steps rounded to bf16
+        # first would bias every hidden gradient by up to 0.4 %
+        s = dloss.detach().to(torch.float32).reshape(1).contiguous()
+        out = torch.empty_like(dh)
+        _lib.call("mmgl_scale", dict(bytes=2.0 * dh.numel() * dh.element_size()), ptr(dh), ptr(s), ptr(out), dh.numel(), dtype_code(dh),
+                  stream_ptr())
+        return out.view(ctx.shape), None, None, None, None
 
 
 def lm_head_cross_entropy(hidden, weight, labels, ignore_index=-100, chunk_rows=8192):

@@ -71,6 +71,52 @@ def test_add_layer_norm_pair(rows, cols, dtype, use_sum, affine_grad):
         assert_close(bd.grad.float(), br.grad, t, "dbeta")
 
 
+@pytest.mark.parametrize("rows,cols", [(37, 64), (640, 2048), (9, 1000)])
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("use_res,affine_grad", [(True, True), (True, False), (False, True)])
+def test_layer_norm_fanout(rows, cols, dtype, use_res, affine_grad):
+    """(r, y) = (x, LN(x)) with both outputs feeding the loss (a pre-LN block: reference :316-320): dx = LN'(dy) + dr from ONE
+    backward kernel, against torch's layer_norm + autograd's own accumulation in fp32."""
+    from mmgl_amd import ops
+    g = torch.Generator().manual_seed(rows * 5 + cols)
+    x = torch.randn(rows, cols, generator=g) * 1.5
+    gamma, beta = torch.randn(cols, generator=g) * 0.2 + 1, torch.randn(cols, generator=g) * 0.1
+    w1, w2 = torch.randn(rows, cols, generator=g), torch.randn(rows, cols, generator=g)
+    xd = dev(x, dtype)
+    gd, bd = (dev(gamma, dtype), dev(beta, dtype)) if affine_grad else (gamma.to(dtype).cuda(), beta.to(dtype).cuda())
+    h = xd * 1.0                                      # a non-leaf input, as in the decoder loop
+    r, y = ops.layer_norm_fanout(h, gd, bd, 1e-5)
+    loss = (y * w1.to(dtype).cuda()).sum() + ((r * w2.to(dtype).cuda()).sum() if use_res else 0)
+    loss.backward()
+    xr, gr, br = (t.detach().float().cpu().requires_grad_() for t in (xd, gd, bd))
+    yr = F.layer_norm(xr, (cols,), gr, br, 1e-5)
+    lr = (yr * w1.to(dtype).float()).sum() + ((xr * w2.to(dtype).float()).sum() if use_res else 0)
+    lr.backward()
+    t = tol(dtype)
+    assert torch.equal(r.detach(), xd.detach())
+    assert torch.equal(y.detach(), ops.layer_norm(xd.detach(), gd.detach(), bd.detach(), 1e-5))      # the same forward kernel
+    assert_close(y.float(), yr, t, "y")
+    assert_close(xd.grad.float(), xr.grad, t, "dx")
+    if affine_grad:
+        assert_close(gd.grad.float(), gr.grad, t, "dgamma")
+        assert_close(bd.grad.float(), br.grad, t, "dbeta")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [5, 4096, 640 * 2048 + 3])
+def test_scale_by_device_scalar(dtype, n):
+    """mmgl_scale: y = x * (*scale) with the product in fp32 (the 1 / grad_accumulation_steps of reference run_generation.py:483)."""
+    from mmgl_amd import _lib
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g).to(dtype).cuda()
+    s = torch.tensor([1.0 / 3.0], dtype=torch.float32, device="cuda")
+    y = torch.empty_like(x)
+    _lib.call("mmgl_scale", None, _lib.ptr(x), _lib.ptr(s), _lib.ptr(y), n, _lib.dtype_code(x), _lib.stream_ptr())
+    assert torch.equal(y, (x.float() * s).to(dtype))
+    _lib.call("mmgl_scale", None, _lib.ptr(x), _lib.ptr(s), _lib.ptr(x), n, _lib.dtype_code(x), _lib.stream_ptr())       # in place
+    assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_add_layer_norm_pair_dropout_matches_unfused(dtype):
     """With dropout the fused pair must reproduce gated_residual(seed) -> layer_norm exactly in forward (same counter
