@@ -50,6 +50,10 @@ def step():
 
 
 WATCH = ("copy_", "add", "add_", "_to_copy", "clone", "cat", "mul", "fill_", "zero_", "index_select", "sum", "contiguous")
+NO_KERNEL = ("view", "empty", "empty_like", "slice", "detach", "as_strided", "alias", "_unsafe_view", "t", "transpose", "unsqueeze", "expand",
+             "permute", "select", "reshape", "squeeze", "empty_strided", "new_empty", "unbind", "split", "narrow", "unflatten", "_reshape_alias",
+             "view_as", "new_empty_strided", "lift_fresh", "split_with_sizes", "chunk")
+ALL_OPS = os.environ.get("STEP_DISPATCH_ALL", "0") == "1"      # every ATen op with a >= 64k-element output, not just the WATCH list
 agg = defaultdict(lambda: [0, 0])
 
 
@@ -57,7 +61,7 @@ class Log(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
         nm = func.__name__.split(".")[0]
-        if nm in WATCH:
+        if nm in WATCH or (ALL_OPS and nm not in NO_KERNEL):
             t = out if isinstance(out, torch.Tensor) else (args[0] if args and isinstance(args[0], torch.Tensor) else None)
             if t is not None and t.is_cuda and t.numel() >= 1 << 16:
                 fr = [f for f in traceback.extract_stack() if "mmgl_amd" in f.filename]
@@ -76,5 +80,5 @@ with Log():
 torch.cuda.synchronize()
 tot = sum(v[1] for v in agg.values())
 print(f"{name} B={B}: {sum(v[0] for v in agg.values())} watched ATen calls on >= 64k-element tensors, {tot / 1e9:.2f} GB of outputs")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
     print(f"{v[1] / 1e6:9.1f} MB x{v[0]:4d}  {k[0]:12s} {str(k[1]):24s} {k[2]:9s} {k[3]}")
