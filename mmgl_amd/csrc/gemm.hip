@@ -314,18 +314,11 @@ inline bool big_tile_shape(int M, int N, int K) { return K % 64 == 0 && (size_t)
 inline constexpr int tune_gemm_8p() { return 1; }
 // few-tile shapes (>= 24 tiles: below that even 8 splits leave most of the chip idle and the 128x128 kernel's 4x finer tiles win)
 inline bool gemm8p_use_splits(int M, int N, int K) {
-    static const int on = [] { const char* e = getenv("MMGL_GEMM_8P_SPLITK"); return e ? atoi(e) : 1; }();
-    return on && cdiv(M, 256) * cdiv(N, 256) >= 24 && gemm8p_splits(M, N, K) > 0;
+    return cdiv(M, 256) * cdiv(N, 256) >= 24 && gemm8p_splits(M, N, K) > 0;
 }
-inline int tune_gemm_8p_min_tiles() {
-    static const int v = [] { const char* e = getenv("MMGL_GEMM_8P_MIN_TILES"); return e ? atoi(e) : 160; }();
-    return v;
-}
+inline constexpr int tune_gemm_8p_min_tiles() { return 160; }
 
-inline int tune_gemm_mid() {
-    static const int v = [] { const char* e = getenv("MMGL_GEMM_MID"); return e ? atoi(e) : 1; }();
-    return v;
-}
+inline constexpr int tune_gemm_mid() { return 1; }       // 1: gemm_mid_kernel takes the few-tile bf16 shapes (round 3: 38.4 -> 32.7 us at 2560x2048x2048)
 inline constexpr int tune_gemm_big() { return 1; }
 
 // out[C,R] = transpose(f(in[R,C])) with f = (* scale) and optional ReLU mask from yact[R,C] (> 0);

@@ -699,7 +699,7 @@ void gemm8p_plan(int M, int N, int K, int* direct, int* nsplit) {
     *direct = tiles;
     *nsplit = 0;
     if (tiles < 160) {
-        static const int min_units = [] { const char* e = getenv("MMGL_GEMM_8P_SPLIT_MIN_UNITS"); return e ? atoi(e) : 24; }();
+        constexpr int min_units = 24;                     // K >= 3072 (tools: 2560 x 2048 x K sweep)
         if (units < min_units) return;
         int s = (224 + tiles - 1) / tiles;
         if (s > 8) s = 8;
@@ -707,7 +707,7 @@ void gemm8p_plan(int M, int N, int K, int* direct, int* nsplit) {
         if (s >= 2) { *direct = 0; *nsplit = s; }
         return;
     }
-    static const int hybrid = [] { const char* e = getenv("MMGL_GEMM_8P_HYBRID"); return e ? atoi(e) : 3; }();   // smallest split count worth it (0 = off)
+    constexpr int hybrid = 3;                             // smallest split count worth it
     const int G = p8_num_cu(), rounds = tiles / G, r = tiles % G;
     if (!hybrid || rounds < 1 || rounds > 3 || r == 0) return;
     int s = G / r;

@@ -1044,12 +1044,6 @@ int sa_check(const char* who, int B, int H, int T, int D, int dtype) {
 
 }  // namespace
 
-// MMGL_SELFATTN_32=0: the 16x16 kernels of this file for bf16 head_dim 64 / 128 too (same-box A/B of selfattn32.hip)
-static bool use_sa32() {
-    static const int on = [] { const char* e = getenv("MMGL_SELFATTN_32"); return e ? atoi(e) : 1; }();
-    return on != 0;
-}
-
 static int sa_ld(const char* who, int& ld, int H, int D) {
     if (ld == 0) ld = H * D;
     MMGL_CHECK_ARG(ld >= H * D && ld % 8 == 0, "%s: row stride %d must be 0 (packed) or a multiple of 8 >= H*D = %d", who, ld, H * D);
@@ -1063,7 +1057,7 @@ extern "C" int mmgl_selfattn_prefix_fwd(const void* q, const void* k, const void
     MMGL_CHECK_ARG(q && k && v && key_valid && out && lse && P >= 0, "mmgl_selfattn_prefix_fwd: bad arguments");
     if ((rc = sa_ld("mmgl_selfattn_prefix_fwd", ld_q, H, D)) || (rc = sa_ld("mmgl_selfattn_prefix_fwd", ld_kv, H, D))) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MMGL_BF16 && use_sa32() && sa32_supported(D, T + P)) return sa32_fwd(q, k, v, key_valid, out, lse, B, H, T, P, D, ld_q, ld_kv, st);
+    if (dtype == MMGL_BF16 && sa32_supported(D, T + P)) return sa32_fwd(q, k, v, key_valid, out, lse, B, H, T, P, D, ld_q, ld_kv, st);
     if (dtype == MMGL_BF16) { SA_DISPATCH(sa_fwd, bf16, q, k, v, key_valid, out, lse, B, H, T, ld_q, P, ld_kv, st) }
     SA_DISPATCH(sa_fwd, float, q, k, v, key_valid, out, lse, B, H, T, ld_q, P, ld_kv, st)
 }
@@ -1089,15 +1083,10 @@ extern "C" int mmgl_selfattn_prefix_bwd(const void* dout, const void* q, const v
     MMGL_CHECK_ARG(workspace_bytes >= mmgl_selfattn_bwd_workspace(B, H, T), "mmgl_selfattn_prefix_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* delta = (float*)workspace;
-    if (dtype == MMGL_BF16 && use_sa32() && sa32_supported(D, T + P)) {
-        static const int parts = [] { const char* e = getenv("MMGL_SELFATTN_32_BWD"); return e ? atoi(e) : 3; }();     // A/B: 1 = dQ only, then the 16x16 dK / dV kernel
-        // head_dim 128: the 32-keys-per-wave dK / dV kernel needs 2 x 64 accumulator registers on top of K^T / V^T (64): it spills;
-        // the 16x16 kernel (32 keys per wave as two 16-key blocks) keeps that half of the backward pass
-        const int p = (D == 128) ? (parts & 1) : parts;
-        rc = sa32_bwd(dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, P, D, ld_q, ld_kv, ld_dq, ld_dkv, p, st);
-        if (rc || (p & 2)) return rc;
-        if (!(p & 1)) { SA_DISPATCH(sa_bwd, bf16, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_q, ld_dq, P, ld_kv, ld_dkv, st) }
-        SA_DISPATCH(sa_bwd, bf16, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_q, ld_dq, P, ld_kv, ld_dkv, st, true)
+    if (dtype == MMGL_BF16 && sa32_supported(D, T + P)) {
+        // dQ (+ delta) kernel, then the dK / dV kernel (head_dim 128: one workgroup per CU, 304 registers; Llama shape 1743 -> 1289 us
+        // against the 16x16 dK / dV kernel it replaced)
+        return sa32_bwd(dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, P, D, ld_q, ld_kv, ld_dq, ld_dkv, 3, st);
     }
     if (dtype == MMGL_BF16) { SA_DISPATCH(sa_bwd, bf16, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_q, ld_dq, P, ld_kv, ld_dkv, st) }
     SA_DISPATCH(sa_bwd, float, dout, q, k, v, out, lse, key_valid, dq, dk, dv, delta, B, H, T, ld_q, ld_dq, P, ld_kv, ld_dkv, st)
@@ -1119,7 +1108,7 @@ extern "C" int mmgl_encattn_fwd(const void* q, const void* k, const void* v, con
     MMGL_CHECK_ARG(ld_in >= H * D && ld_out >= H * D && ld_in % 8 == 0 && ld_out % 8 == 0,
                    "mmgl_encattn_fwd: row strides (%d, %d) must be >= H*D = %d and multiples of 8 elements", ld_in, ld_out, H * D);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MMGL_BF16 && use_sa32() && sa32_supported(D, max_len)) return sa32_enc_fwd(q, k, v, cu_seqlens, out, nseq, H, D, ld_in, ld_out, max_len, q_rows, st);
+    if (dtype == MMGL_BF16 && sa32_supported(D, max_len)) return sa32_enc_fwd(q, k, v, cu_seqlens, out, nseq, H, D, ld_in, ld_out, max_len, q_rows, st);
     if (dtype == MMGL_BF16) { SA_DISPATCH(enc_fwd, bf16, q, k, v, cu_seqlens, out, nseq, H, ld_in, ld_out, max_len, q_rows, st) }
     SA_DISPATCH(enc_fwd, float, q, k, v, cu_seqlens, out, nseq, H, ld_in, ld_out, max_len, q_rows, st)
 }

@@ -49,6 +49,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef SA32_NS_DKV
 #define SA32_NS_DKV 2             // ring slots of the dK / dV kernel (Q / dO tiles + row statistics)
 #endif
+#ifndef SA32_NS_DKV128
+#define SA32_NS_DKV128 2          // ... at head_dim 128 (one workgroup per CU: up to 4 slots of 33 KiB fit)
+#endif
 #ifndef SA32_TRACE
 #define SA32_TRACE 0              // timing experiments only: wall-clock stamps of every workgroup of the forward kernel (MMGL_SA32_TRACE = device pointer)
 #endif
@@ -675,13 +678,13 @@ __global__ __launch_bounds__(256, 2) void sa32_bwd_dq_kernel(SA32BwdArgs a) {
 template <int D> struct GB32 {
     typedef G32<D> G;
     static constexpr int SLOTB = 2 * G::TILEB + 1024;                    // Q tile, dO tile, lse[64], delta[64], padding
-    static constexpr int NS = SA32_NS_DKV;
+    static constexpr int NS = (D == 64) ? SA32_NS_DKV : SA32_NS_DKV128;
     static constexpr int LDS = NS * SLOTB;
     static constexpr int NPB = 2 * G::PIECES / 4 + 2;                    // LDS-DMA instructions per wave and tile
 };
 
 template <int D>
-__global__ __launch_bounds__(256, 2) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
     typedef G32<D> G;
     typedef GB32<D> GB;
     constexpr int NS = GB::NS, PD = NS - 1;
@@ -963,8 +966,7 @@ int sa32_bwd(const void* dout, const void* q, const void* k, const void* v, cons
     int rc = MMGL_OK;
     if (parts & 1) rc = D == 64 ? launch_bwd_dq<64>(a, st) : launch_bwd_dq<128>(a, st);
     if (rc == MMGL_OK && (parts & 2)) {
-        if (D != 64) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "sa32_bwd: the dK / dV kernel covers head_dim 64 only");
-        rc = launch_bwd_dkv<64>(a, st);
+        rc = D == 64 ? launch_bwd_dkv<64>(a, st) : launch_bwd_dkv<128>(a, st);
     }
     return rc;
 }
