@@ -1102,6 +1102,25 @@ def _ffn_pitch(M, N, K, dtype):
     return N
 
 
+_CU_COUNT = {}
+
+
+def _round_split_rows(M, N, device):
+    """Rows [0, m1) of an [M, N] GEMM output that fill whole rounds of the persistent kernel's 256 x 256 tiles, when the rest is a
+    short tail: at the reference's batch (M = 4 * 640 = 2560, reference language_modelling/run_generation.py:124-126) the FFN's
+    [2560, 8192] output is 320 tiles on 256 CUs -- a second round at a quarter of the chip (102.6 us); 2048 rows on the persistent
+    kernel + 512 rows on the few-tile kernel take 78.3 us (tools/probes/gemm_msplit.py).  0 = do not split."""
+    G = _CU_COUNT.get(device.index)
+    if G is None:
+        G = _CU_COUNT[device.index] = torch.cuda.get_device_properties(device).multi_processor_count
+    tm, tn = (M + 255) // 256, (N + 255) // 256
+    rounds, rem = divmod(tm * tn, G)
+    if not (1 <= rounds <= 3 and 0 < rem <= G // 4) or (rounds * G) % tn:
+        return 0
+    m1 = rounds * G // tn * 256
+    return m1 if 0 < m1 < M else 0
+
+
 def _row_strided(t2, cols, n_out):
     """t2 [M, cols] as a GEMM operand: itself when it is row-major with unit column stride and a row pitch the fast path
     takes, else a contiguous copy."""
@@ -1122,7 +1141,7 @@ _HANDOVER.relu_bits = None
 
 class _FrozenLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act, mask_dx, premasked, residual=None, relu_bits=None, relu_pitch=0):
+    def forward(ctx, x, weight, bias, act, mask_dx, premasked, residual=None, relu_bits=None, relu_pitch=0, relu_rows=0):
         require_cuda(x, weight)
         K, N = weight.shape[1], weight.shape[0]
         x2 = _row_strided(x.reshape(-1, K), K, N)
@@ -1136,11 +1155,20 @@ class _FrozenLinear(torch.autograd.Function):
             if pitch != N:                   # fc1 of a frozen FFN: the consumer (fc2, mask_dx) reads it with its row stride
                 out = torch.empty(*x.shape[:-1], pitch, dtype=x.dtype, device=x.device)[..., :N]
                 wc = w.contiguous()
-                if act == 1 and relu_bits_bytes(x2.shape[0], N, K, x2.stride(0), K, pitch, x.dtype):
+                M_ = x2.shape[0]
+                m1 = _round_split_rows(M_, N, x.device) if act == 1 else 0
+                if m1 and relu_bits_bytes(m1, N, K, x2.stride(0), K, pitch, x.dtype):
+                    # a 1.25-round output: whole rounds on the persistent kernel (mask bits), the short tail on the few-tile kernel
+                    # (its rows of the activation stay the mask of fc2's backward)
+                    y = out.reshape(-1, N)
+                    _, bits = gemm_nt_relu_bits(x2[:m1], wc, b, y[:m1])
+                    gemm_nt(x2[m1:], wc, b, act=1, out=y[m1:])
+                    _HANDOVER.relu_bits = (bits, pitch, m1)
+                elif act == 1 and relu_bits_bytes(M_, N, K, x2.stride(0), K, pitch, x.dtype):
                     # the ReLU mask leaves as bits beside the activation: fc2's backward applies those (16 bytes per lane and
                     # tile) instead of re-reading -- and keeping -- the [M, ffn] activation
                     y, bits = gemm_nt_relu_bits(x2, wc, b, out.reshape(-1, N))
-                    _HANDOVER.relu_bits = (bits, pitch)
+                    _HANDOVER.relu_bits = (bits, pitch, M_)
                 else:
                     y = gemm_nt(x2, wc, b, act=act, out=out.reshape(-1, N))
             else:
@@ -1159,9 +1187,14 @@ class _FrozenLinear(torch.autograd.Function):
         ctx.mask_bits = None
         xkeep = x2 if mask_dx else None
         if mask_dx and relu_bits is not None:
-            if x2.dtype == torch.bfloat16 and x2.stride(0) == relu_pitch and N % 128 == 0 and \
-                    relu_bits_bytes(x2.shape[0], K, N, N, N, relu_pitch, x2.dtype) == relu_bits.numel():
-                ctx.mask_bits, xkeep = (relu_bits, relu_pitch), None
+            mrows = relu_rows or x2.shape[0]                  # rows the bits cover (the rest: the activation rows themselves)
+            if x2.dtype == torch.bfloat16 and x2.stride(0) == relu_pitch and N % 128 == 0 and 0 < mrows <= x2.shape[0] and \
+                    relu_bits_bytes(mrows, K, N, N, N, relu_pitch, x2.dtype) == relu_bits.numel():
+                ctx.mask_bits = (relu_bits, relu_pitch, mrows)
+                xkeep = None
+                if mrows < x2.shape[0]:      # a short tail, copied (a view would keep the [M, ffn] buffer) with the row pitch the dgrad's output has
+                    xkeep = torch.empty(x2.shape[0] - mrows, relu_pitch, dtype=x2.dtype, device=x2.device)[:, :K]
+                    xkeep.copy_(x2[mrows:])
         ctx.save_for_backward(weight, y if (act == 1 and not premasked) else None, xkeep)
         ctx.act = 0 if premasked else act
         ctx.xshape = x.shape
@@ -1180,12 +1213,17 @@ class _FrozenLinear(torch.autograd.Function):
         elif ctx.act:
             raise RuntimeError("frozen_linear: only the ReLU epilogue is differentiable")
         if ctx.mask_bits is not None:
-            bits, pitch = ctx.mask_bits
+            bits, pitch, mrows = ctx.mask_bits
             buf = torch.empty(g.shape[0], pitch, dtype=g.dtype, device=g.device)[:, :K]
-            dx = frozen_dgrad(g, weight, out=buf, bits=bits)
+            if mrows < g.shape[0]:                            # whole rounds with the mask bits, the tail rows with their activation rows
+                frozen_dgrad(g[:mrows], weight, out=buf[:mrows], bits=bits)
+                frozen_dgrad(g[mrows:], weight, zmask=xmask, out=buf[mrows:])
+                dx = buf
+            else:
+                dx = frozen_dgrad(g, weight, out=buf, bits=bits)
         else:
             dx = frozen_dgrad(g, weight, zmask=xmask)
-        return dx.reshape(ctx.xshape), None, None, None, None, None, (dy if ctx.has_resid else None), None, None
+        return dx.reshape(ctx.xshape), None, None, None, None, None, (dy if ctx.has_resid else None), None, None, None
 
 
 def frozen_linear(x, weight, bias, relu=False, mask_dx=False, bwd_premasked=False, act=None, residual=None):
@@ -1208,7 +1246,8 @@ def frozen_linear(x, weight, bias, relu=False, mask_dx=False, bwd_premasked=Fals
         raise ValueError("frozen_linear: `residual` ([..., out_features], added in the GEMM epilogue) goes with no activation")
     _HANDOVER.relu_bits = None
     mb = getattr(x, "_mmgl_relu_bits", None) if mask_dx else None
-    y = _FrozenLinear.apply(x, weight, bias, code, bool(mask_dx), bool(bwd_premasked), residual, None if mb is None else mb[0], 0 if mb is None else mb[1])
+    y = _FrozenLinear.apply(x, weight, bias, code, bool(mask_dx), bool(bwd_premasked), residual, None if mb is None else mb[0], 0 if mb is None else mb[1],
+                            0 if mb is None else mb[2])
     if _HANDOVER.relu_bits is not None:                      # fc1 of a frozen FFN left its ReLU mask as bits: hand them to the consumer
         y._mmgl_relu_bits, _HANDOVER.relu_bits = _HANDOVER.relu_bits, None
     return y
