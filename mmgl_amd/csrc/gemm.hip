@@ -319,6 +319,27 @@ inline bool gemm8p_use_splits(int M, int N, int K) {
 inline constexpr int tune_gemm_8p_min_tiles() { return 160; }
 
 inline constexpr int tune_gemm_mid() { return 1; }       // 1: gemm_mid_kernel takes the few-tile bf16 shapes (round 3: 38.4 -> 32.7 us at 2560x2048x2048)
+// Row split of an output of one to three rounds of 256x256 tiles plus a short remainder (the reference's batch: [2560, 8192] = 320
+// tiles on 256 CUs, a second round at a quarter of the chip): rows [0, m1) = the whole rounds on the persistent kernel, the tail rows
+// on the few-tile kernel -- 102.6 -> 78.3 us at 2560x8192x2048 (tools/probes/gemm_msplit.py).  0 = no split.
+inline int gemm8p_row_split(int M, int N, int K, int ldx, int ldw, int ldy) {
+    const int G = gemm8p_num_cu(), tm = cdiv(M, 256), tn = cdiv(N, 256);
+    const int rounds = tm * tn / G, rem = tm * tn % G;
+    if (rounds < 1 || rounds > 3 || rem == 0 || rem > G / 4 || (rounds * G) % tn) return 0;
+    const int m1 = rounds * G / tn * 256;
+    return (m1 > 0 && m1 < M && gemm_mid_supported(M - m1, N, K, ldx, ldw, ldy)) ? m1 : 0;
+}
+// launch_gemm8p with that split applied (no K-split scratch: the callers below bring none or use it for other plans)
+inline int launch_gemm8p_rows(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, const bf16* resid, const bf16* zmask,
+                              int M, int N, int K, int act, float scale, hipStream_t st, float* part = nullptr, size_t part_bytes = 0) {
+    const int m1 = gemm8p_row_split(M, N, K, ldx, ldw, ldy);
+    if (!m1) return launch_gemm8p(X, ldx, W, ldw, Y, ldy, bias, resid, zmask, M, N, K, act, scale, st, part, part_bytes);
+    int rc = launch_gemm8p(X, ldx, W, ldw, Y, ldy, bias, resid, zmask, m1, N, K, act, scale, st);
+    if (rc) return rc;
+    const size_t o = (size_t)m1 * ldy;
+    return launch_gemm_mid(X + (size_t)m1 * ldx, ldx, W, ldw, Y + o, ldy, bias, resid ? resid + o : nullptr, zmask ? zmask + o : nullptr, M - m1, N, K,
+                           act, scale, st);
+}
 inline constexpr int tune_gemm_big() { return 1; }
 
 // out[C,R] = transpose(f(in[R,C])) with f = (* scale) and optional ReLU mask from yact[R,C] (> 0);
@@ -394,7 +415,7 @@ int launch_gemm(const T* X, const T* W, T* Y, const T* bias, int M, int N, int K
         // persistent ping-pong kernel (gemm8p.hip) whenever the shape gives it enough 256x256 tiles
         if (!X2 && !accumulate && tune_gemm_8p() && gemm8p_supported(M, N, K, K, K, N) && cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles()) {
             if (zmask_done) *zmask_done = zmask != nullptr;
-            return launch_gemm8p((const bf16*)X, K, (const bf16*)W, K, (bf16*)Y, N, (const bf16*)bias, nullptr, (const bf16*)zmask, M, N, K, act, scale, st);
+            return launch_gemm8p_rows((const bf16*)X, K, (const bf16*)W, K, (bf16*)Y, N, (const bf16*)bias, nullptr, (const bf16*)zmask, M, N, K, act, scale, st);
         }
         // big-tile kernel when the shape fills the chip with 256x256 tiles (>= 2 tiles per CU keeps the tail small)
         if (!X2 && tune_gemm_big() && big_tile_shape(M, N, K)) {
@@ -1201,7 +1222,7 @@ int linear_bwd(const T* dy, const T* y, const T* x, const T* W, T* dx, T* dW, T*
                 if (!rc && tune_gemm_8p() && gemm8p_supported(M, K, N, N, N, K) && gemm8p_use_splits(M, K, N)) {
                     // few tiles, or a remainder of a round of tiles (the reference's batch): K-split work items, scratch tiles in
                     // the region the weight gradient's split partials use afterwards (same stream: the dgrad has consumed them by then)
-                    rc = launch_gemm8p((const bf16*)a, N, (const bf16*)Wt, N, (bf16*)dx, K, nullptr, nullptr, mask_dx ? (const bf16*)x : nullptr,
+                    rc = launch_gemm8p_rows((const bf16*)a, N, (const bf16*)Wt, N, (bf16*)dx, K, nullptr, nullptr, mask_dx ? (const bf16*)x : nullptr,
                                        M, K, N, MMGL_ACT_NONE, sc, st, (float*)(ws + bf16_part_offset(M, N, K, act)), gemm8p_split_bytes(M, K, N));
                     masked = mask_dx;
                 } else if (!rc)
@@ -1314,8 +1335,8 @@ extern "C" int mmgl_gemm_nt(const void* x, int ldx, const void* W, int ldw, cons
     hipStream_t st = (hipStream_t)stream;
     // few-tile shapes run as K-split work items when the caller brought mmgl_gemm_nt_workspace() bytes, unsplit otherwise
     if (gemm_nt_on_8p(M, N, K, ldx, ldw, ldy, dtype))
-        return launch_gemm8p((const bf16*)x, ldx, (const bf16*)W, ldw, (bf16*)y, ldy, (const bf16*)bias, (const bf16*)residual,
-                             (const bf16*)zmask, M, N, K, act, out_scale, st, (float*)workspace, workspace_bytes);
+        return launch_gemm8p_rows((const bf16*)x, ldx, (const bf16*)W, ldw, (bf16*)y, ldy, (const bf16*)bias, (const bf16*)residual,
+                                  (const bf16*)zmask, M, N, K, act, out_scale, st, (float*)workspace, workspace_bytes);
     if (dtype == MMGL_BF16 && tune_gemm_mid() && gemm_mid_supported(M, N, K, ldx, ldw, ldy))
         return launch_gemm_mid((const bf16*)x, ldx, (const bf16*)W, ldw, (bf16*)y, ldy, (const bf16*)bias, (const bf16*)residual,
                                (const bf16*)zmask, M, N, K, act, out_scale, st);

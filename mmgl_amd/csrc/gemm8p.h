@@ -6,6 +6,7 @@
 // row strides ldx / ldw / ldy in elements (resid and zmask share ldy)
 bool gemm8p_supported(int M, int N, int K, int ldx, int ldw, int ldy);
 int gemm8p_splits(int M, int N, int K);      // K splits for few-tile outputs (0 = none)
+int gemm8p_num_cu();                          // workgroups of a full launch (= CUs of the current device)
 size_t gemm8p_split_bytes(int M, int N, int K);   // fp32 partial tiles of the K-split path (caller's scratch)
 int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, const bf16* resid,
                   const bf16* zmask, int M, int N, int K, int act, float scale, hipStream_t st, float* part = nullptr,

@@ -694,6 +694,7 @@ static int p8_num_cu() {
     }
     return n;
 }
+int gemm8p_num_cu() { return p8_num_cu(); }
 void gemm8p_plan(int M, int N, int K, int* direct, int* nsplit) {
     const int tiles = cdiv(M, 256) * cdiv(N, 256), units = K / 128;
     *direct = tiles;
