@@ -44,9 +44,10 @@ CASES = [
     (2560, 2048, 8192, 1, True, False, False, 1.0),      # the reference's batch of 4 (80 tiles): K-split work items + finish kernel
     (2600, 2048, 6144, 3, True, True, False, 0.5),       # uneven K splits (48 steps over 3), ragged M, residual, scale
     (2560, 2064, 3072, 0, False, False, True, 1.0),      # K split with a ragged last column tile and the zmask applied by the finish kernel
-    (2560, 8192, 2048, 1, True, False, False, 1.0),      # 320 tiles on 256 CUs: one round of whole tiles + the other 64 as 4 K-split items each
+    (2560, 8192, 2048, 1, True, False, False, 1.0),      # 320 tiles on 256 CUs: 2048 rows = one round of the persistent kernel + 512 tail rows on the few-tile kernel
+    (2560, 8192, 2048, 0, True, True, True, 0.5),        # the same row split with zmask + residual (both offset to the tail rows) and a scale
     (2570, 8200, 2048, 0, True, True, True, 0.5),        # the same with ragged last tile row / column (363 tiles), zmask + residual in the finish kernel
-    (2560, 8192, 4096, 3, False, False, False, 1.0),     # hybrid plan, 8-way remainder capped by its K steps
+    (2560, 8192, 4096, 3, False, False, False, 1.0),     # the row split at K = 4096, quick-GELU
     (1024, 512, 256, 1, True, False, False, 1.0),        # few tiles: the 128x128 kernel (csrc/gemm_mid.hip)
     (300, 96, 64, 2, True, True, True, 2.0),             # tiny, one K step, ragged rows and columns, every epilogue stage
     (2560, 2048, 2048, 0, True, True, False, 1.0),       # out_proj at the reference's batch of 4: 320 tiles of 128x128, two workgroups per CU
