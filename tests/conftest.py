@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # bring libmmgl_hip.so up to date with its sources before anything imports it (a no-op when it is; a fresh checkout or an edited
+    # kernel otherwise leaves the suite running against a missing / stale library).  Where hipcc is absent the prebuilt .so is used as is.
+    from mmgl_amd import _build
+    if os.path.exists(_build.HIPCC):
+        _build.build(verbose=False)
 
 
 def pytest_collection_modifyitems(config, items):
