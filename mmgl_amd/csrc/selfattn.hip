@@ -947,18 +947,16 @@ int sa_fwd(const void* q, const void* k, const void* v, const uint8_t* valid, vo
 
 template <typename T, int D>
 int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, const uint8_t* valid,
-           void* dq, void* dk, void* dv, float* delta, int B, int H, int T_, int ldq, int ldg, int P, int ldk, int ldgk, hipStream_t st,
-           bool dkv_only = false) {
+           void* dq, void* dk, void* dv, float* delta, int B, int H, int T_, int ldq, int ldg, int P, int ldk, int ldgk, hipStream_t st) {
     // ldq / ldg: row strides of q / dq; ldk / ldgk: of k, v / dk, dv ([B, P + T] rows); P prefix keys (0 = plain causal attention)
-    // dkv_only: delta and dq have been produced already (selfattn32.hip's first backward kernel)
-    if (!dkv_only) {
+    {
         const size_t total = (size_t)B * T_ * H * (D / 8);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL((rowdot_kernel<T, D>), dim3(blocks), dim3(256), 0, st, (const T*)dout, (const T*)out, delta, B, H, T_);
         MMGL_CHECK_LAUNCH("selfattn_rowdot");
     }
-    if (!dkv_only) {
+    {
         typedef XC<T, D, 4, 2> C;
         const int QB = 4 * 16 * C::QT, nqb = cdiv(T_, QB);
         const size_t lds = 2 * (sizeof(T) * ((C::TIMG ? C::RMIMG : C::ROWIMG) + C::ROWIMG) + KT);
