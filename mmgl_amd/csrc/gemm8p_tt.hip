@@ -366,12 +366,15 @@ int gemm8p_tt_splits(int RA, int RB, int M) {
     if (M % 128) return 0;
     if (RA % 256 || RB % 256)                        // ragged outputs (lm_head: 50272 rows): unsplit only, when the tiles fill the chip
         return (RA % 8 == 0 && RB % 8 == 0 && M >= 256 && cdiv(RA, 256) * cdiv(RB, 256) >= 192) ? 1 : 0;
-    const int tiles = (RA / 256) * (RB / 256);
-    int best = 0;
-    for (int s = 1; s <= 16; s *= 2) {
-        if (M % (128 * s) || M / s < 256) break;
-        best = s;
-        if (tiles * s >= 192) return s;
+    // every split count that cuts the M rows into equal runs of whole 128-row steps, priced as rounds of work items x (steps per item +
+    // ~3 steps of per-item fixed cost): a 768 x 768 gradient over 40960 rows (9 tiles) takes 20 splits (180 items of 16 steps) instead
+    // of 16 (144 items of 20), a 3072 x 768 one 5 (180 x 64) instead of 8 (288 items = two rounds of 40)
+    const int tiles = (RA / 256) * (RB / 256), units = M / 128, G = gemm8p_num_cu();
+    int best = 0, best_cost = 0;
+    for (int s = 1; s <= 32; ++s) {
+        if (units % s || M / s < 256) continue;
+        const int cost = cdiv(tiles * s, G) * (units / s + 3);
+        if (!best || cost < best_cost) { best = s; best_cost = cost; }
     }
     return (best && tiles * best >= 64) ? best : 0;
 }
