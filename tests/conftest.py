@@ -14,7 +14,13 @@ def pytest_configure(config):
     # kernel otherwise leaves the suite running against a missing / stale library).  Where hipcc is absent the prebuilt .so is used as is.
     from mmgl_amd import _build
     if os.path.exists(_build.HIPCC):
-        _build.build(verbose=False)
+        try:
+            _build.build(verbose=False)
+        except Exception as e:             # keep a usable prebuilt library usable; tests/test_abi_cpu.py still fails on a stale one
+            if not os.path.exists(_build.LIB):
+                raise
+            import warnings
+            warnings.warn(f"could not rebuild libmmgl_hip.so ({e}); running against the existing one")
 
 
 def pytest_collection_modifyitems(config, items):
