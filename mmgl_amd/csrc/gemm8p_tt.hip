@@ -366,14 +366,16 @@ int gemm8p_tt_splits(int RA, int RB, int M) {
     if (M % 128) return 0;
     if (RA % 256 || RB % 256)                        // ragged outputs (lm_head: 50272 rows): unsplit only, when the tiles fill the chip
         return (RA % 8 == 0 && RB % 8 == 0 && M >= 256 && cdiv(RA, 256) * cdiv(RB, 256) >= 192) ? 1 : 0;
-    // every split count that cuts the M rows into equal runs of whole 128-row steps, priced as rounds of work items x (steps per item +
-    // ~3 steps of per-item fixed cost): a 768 x 768 gradient over 40960 rows (9 tiles) takes 20 splits (180 items of 16 steps) instead
-    // of 16 (144 items of 20), a 3072 x 768 one 5 (180 x 64) instead of 8 (288 items = two rounds of 40)
+    // every split count that cuts the M rows into equal runs of whole 128-row steps, priced in 128-row steps (~1.7 us of a CU):
+    // rounds of work items x (steps per item + ~3 of per-item fixed cost), and for a split the fp32 partial tiles -- 3 more steps per
+    // item to write them plus 0.06 per partial tile for the fold (256 KiB written and read back at ~5 TB/s, chip-wide).  A 768 x 768
+    // gradient over 40960 rows (9 tiles) takes 20 splits (180 items of 16 steps) instead of 16 (144 of 20), a 3072 x 768 one 5
+    // (180 x 64) instead of 8 (288 items = two rounds of 40); 64 tiles stay at 4 splits, outputs of >= 256 tiles unsplit.
     const int tiles = (RA / 256) * (RB / 256), units = M / 128, G = gemm8p_num_cu();
     int best = 0, best_cost = 0;
     for (int s = 1; s <= 32; ++s) {
         if (units % s || M / s < 256) continue;
-        const int cost = cdiv(tiles * s, G) * (units / s + 3);
+        const int cost = cdiv(tiles * s, G) * (units / s + 3) + (s > 1 ? 3 + tiles * s * 6 / 100 : 0);
         if (!best || cost < best_cost) { best = s; best_cost = cost; }
     }
     return (best && tiles * best >= 64) ? best : 0;
