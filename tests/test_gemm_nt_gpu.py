@@ -46,6 +46,8 @@ CASES = [
     (2560, 2064, 3072, 0, False, False, True, 1.0),      # K split with a ragged last column tile and the zmask applied by the finish kernel
     (2560, 8192, 2048, 1, True, False, False, 1.0),      # 320 tiles on 256 CUs: 2048 rows = one round of the persistent kernel + 512 tail rows on the few-tile kernel
     (2560, 8192, 2048, 0, True, True, True, 0.5),        # the same row split with zmask + residual (both offset to the tail rows) and a scale
+    (2400, 8192, 2048, 1, True, True, True, 1.0),        # the row split with a ragged tail (2048 + 352 rows), every epilogue stage
+    (4700, 8192, 2048, 3, True, False, False, 1.0),      # two whole rounds (4096 rows) + a 604-row tail
     (2570, 8200, 2048, 0, True, True, True, 0.5),        # the same with ragged last tile row / column (363 tiles), zmask + residual in the finish kernel
     (2560, 8192, 4096, 3, False, False, False, 1.0),     # the row split at K = 4096, quick-GELU
     (1024, 512, 256, 1, True, False, False, 1.0),        # few tiles: the 128x128 kernel (csrc/gemm_mid.hip)
