@@ -212,6 +212,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=1)
+    ap.add_argument("--force-exchange", action="store_true", help="--gpus 1 only: create a world_size-1 RCCL ('nccl') process group on the GPU and run "
+                    "the data-parallel engine with its gradient exchange forced on (hook-launched async all-reduces, work.wait(), dynamic GEMM "
+                    "tile schedule), reporting the `exchange` block: the device-side N>1 path on a 1-GPU box")
     ap.add_argument("--ref-batch", type=int, default=4, help="also report the step at the reference's default per-device batch (Arguments default 4, run_generation.py:124-126); 0 = skip")
     args = ap.parse_args()
 
@@ -240,12 +243,23 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     import torch.distributed as dist
+    forced = bool(args.force_exchange) and world == 1
+    if args.force_exchange and world != 1:
+        raise SystemExit("--force-exchange is the 1-GPU stand-in for the N>1 exchange: use it with --gpus 1")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    elif forced:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                **(dict(device_id=device) if backend == "nccl" else {}))
+    comm = world > 1 or forced                        # collectives are issued (RCCL) -- with one rank only under --force-exchange
 
     from mmgl_amd import _lib
     from mmgl_amd.distributed import DataParallelEngine
@@ -277,7 +291,7 @@ def main():
                 p.normal_(std=0.02)                   # numerically live adapters (init value 0 = identity)
     model = model.to(dtype).to(device)
     model.train()
-    engine = DataParallelEngine(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.01)
+    engine = DataParallelEngine(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.01, force_exchange=forced)
     n_train = sum(p.numel() for p in engine.params)
 
     batch, valid_keys = synthetic_batch(args.batch, cfg, seed=1234 + rank, device=device)
@@ -366,7 +380,7 @@ def main():
 
     # ---- gradient-exchange report (outside the timed region; every rank runs the same collectives)
     exchange = None
-    if world > 1:
+    if comm:
         ones = torch.ones(1, device=device)
         dist.all_reduce(ones)                                         # = number of ranks RCCL actually connected
         bytes_per_step = engine.exchange_bytes / max(1, n_steps_run[0])
@@ -393,7 +407,7 @@ def main():
         engine.sync = True
         step_s = dt / args.steps
         exposed = max(0.0, step_s - nosync_s)
-        exchange = {"rccl_ranks": int(ones.item()), "backend": backend, "buckets": len(engine.buckets),
+        exchange = {"rccl_ranks": int(ones.item()), "backend": backend, "forced": forced, "buckets": len(engine.buckets),
                     "exchange_bytes_per_step_per_gpu": int(bytes_per_step),
                     "wire_bytes_per_step_per_gpu": int(2 * (world - 1) / world * bytes_per_step),
                     "allreduce_ms_alone": round(ar_s * 1e3, 3), "step_ms_without_exchange": round(nosync_s * 1e3, 3),
@@ -474,7 +488,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and cfg["kind"] == "flamingo":
             line["cpu_baseline"] = cpu_baseline(model, cfg, lm_cfg, batch, args.cpu_samples)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if comm:
         dist.destroy_process_group()
 
 

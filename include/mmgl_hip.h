@@ -20,7 +20,10 @@
  *     The Python shim maps INVALID/UNSUPPORTED to ValueError (the reference raises ValueError for
  *     shape / mode mismatches, modelling_cross_attention.py:160-164,214-224,260-264) and HIP to
  *     RuntimeError.
- *   - re-entrant; no global state except the last-error string (thread-local).
+ *   - re-entrant.  Global state: the last-error string (thread-local), and ONE opt-in per-device setting, the dynamic tile
+ *     schedule of the persistent GEMM (mmgl_gemm_set_tile_counter below): while it is set, that device's persistent-GEMM launches
+ *     are bound to one stream (the first one that launches after the call) and a launch on another stream returns
+ *     MMGL_ERR_INVALID.  With the default static schedule nothing is shared between calls.
  */
 #ifndef MMGL_HIP_H
 #define MMGL_HIP_H
@@ -285,7 +288,9 @@ int mmgl_relu_bwd(const void* dy, const void* y, void* out, size_t n, int dtype,
  *   counter: DEVICE pointer to 16 uint32, all zero, owned by the caller and left all zero by every launch; NULL (the default)
  *   = static schedule.  The setting belongs to the CURRENT DEVICE (hipGetDevice of the caller), process-wide: it also applies to
  *   launches from other host threads -- autograd runs the backward GEMMs, the ones that overlap the collective, on its own device
- *   thread.  GEMMs of that device must not run concurrently on two streams while a counter is set (they would share it).
+ *   thread.  The counters serve ONE stream per device: the first persistent-GEMM launch after this call binds them to its stream,
+ *   and a launch of that device on any other stream while they are set returns MMGL_ERR_INVALID (two launches in flight would hand
+ *   out each other's tiles); setting the counter again (or NULL) releases the binding.
  *   mmgl_gemm_get_tile_counter: the current device's counter (NULL: static schedule). */
 int mmgl_gemm_set_tile_counter(void* counter);
 void* mmgl_gemm_get_tile_counter(void);

@@ -11,6 +11,7 @@ import torch  # imported first on purpose: the .so must bind to the HIP runtime 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMGL_LIB_PATH") or os.path.join(_HERE, "libmmgl_hip.so")     # override: timing experiments with ablated builds
 
+ABI_VERSION = 102         # = mmgl_version() of the library this binding was written against (csrc/lib.hip)
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
 _ERR_INVALID, _ERR_UNSUPPORTED, _ERR_HIP = 1, 2, 3
@@ -90,6 +91,10 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m mmgl_amd._build` "
                 "(or __graft_entry__.build()). mmgl_amd has no CPU fallback.")
         h = ctypes.CDLL(LIB_PATH)
+        h.mmgl_version.restype = ctypes.c_int
+        if h.mmgl_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {h.mmgl_version()}, this binding expects {ABI_VERSION}: a stale build -- "
+                               "run `python -m mmgl_amd._build --force`")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res

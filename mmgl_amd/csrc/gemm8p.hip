@@ -492,8 +492,14 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     bf16x8 fx[2][4], fwA[2][2], fwB[2][2];
     fetch_bias(n0, 0);                   // the lane's 16 bias values of the first tile
     if (dyn && tid == 0) {               // the next two work items of this workgroup (one lane asks, the mailbox tells the other waves)
-        mailbox[0] = p8_fetch_item(a.sched, xcd, nlists, G, Gx, a.total * a.nsplit);
-        mailbox[1] = p8_fetch_item(a.sched, xcd, nlists, G, Gx, a.total * a.nsplit);
+        // A workgroup never holds more items up front than the static schedule would give it, ceil(items / G): with three claims per
+        // workgroup before any work is done, an output of one round of tiles was computed by a third of the CUs (3 tile times instead
+        // of 1) and one of two rounds by 128 workgroups with three tiles + 128 with one (3 instead of 2).  From three rounds up
+        // the claims are as before: two in the prologue, then one per finished tile.
+        const int nit = a.total * a.nsplit, cap = (nit + G - 1) / G;
+        const int i1 = cap >= 2 ? p8_fetch_item(a.sched, xcd, nlists, G, Gx, nit) : -1;
+        mailbox[0] = i1;
+        mailbox[1] = (cap >= 3 && i1 >= 0) ? p8_fetch_item(a.sched, xcd, nlists, G, Gx, nit) : -1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 #if P8_RELAX
@@ -581,8 +587,10 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
             // dynamic schedule: one lane asks for the item after the next one now -- the answer comes back under the epilogue -- and
             // leaves it in the mailbox slot of this tile's parity, which every wave reads at the NEXT tile switch (a whole tile and
             // dozens of barriers from now; the other slot is the one being read at this switch)
+            // (only when the tile after the next one exists -- slot (it + 1) & 1, written a switch ago by this same lane: a fetch whose
+            // slot is never read again would take an item out of the lists for good)
             int fetched = -1;
-            if (dyn && tid == 0 && have_next) fetched = p8_fetch_item(a.sched, xcd, nlists, G, Gx, a.total * a.nsplit);
+            if (dyn && tid == 0 && have_next && mailbox[(it + 1) & 1] >= 0) fetched = p8_fetch_item(a.sched, xcd, nlists, G, Gx, a.total * a.nsplit);
 #if !(P8_ABLATE & 1)
             epilogue();
 #endif
@@ -738,11 +746,29 @@ size_t gemm8p_split_bytes(int M, int N, int K) {
 // switched the schedule on (a thread_local pointer left exactly those launches on the static schedule).
 static std::atomic<unsigned*> g_tile_counter[64];
 static std::atomic<int> g_tile_counters_set{0};
+// The one counter block of a device serves ONE stream: two launches in flight on different streams would hand out each other's
+// tiles.  The first launch after mmgl_gemm_set_tile_counter binds the device's counters to its stream; a launch on any other stream
+// while they are set is refused (MMGL_ERR_INVALID) instead of corrupting both schedules.
+static hipStream_t const P8_STREAM_UNBOUND = (hipStream_t)(intptr_t)-1;
+static std::atomic<hipStream_t> g_tile_stream[64];
 static unsigned* p8_tile_counter() {
     if (!g_tile_counters_set.load(std::memory_order_relaxed)) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     return g_tile_counter[dev & 63].load(std::memory_order_acquire);
+}
+// counters for a launch on stream `st` (NULL: static schedule); false: the device's counters belong to another stream
+static bool p8_tile_counter_for(hipStream_t st, unsigned** out) {
+    *out = nullptr;
+    if (!g_tile_counters_set.load(std::memory_order_relaxed)) return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    unsigned* c = g_tile_counter[dev & 63].load(std::memory_order_acquire);
+    if (!c) return true;
+    hipStream_t bound = P8_STREAM_UNBOUND;
+    if (!g_tile_stream[dev & 63].compare_exchange_strong(bound, st, std::memory_order_acq_rel) && bound != st) return false;
+    *out = c;
+    return true;
 }
 
 int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, const bf16* resid,
@@ -785,7 +811,9 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
     a.trace = nullptr;
     a.trace_wg = 0;
     a.tile0 = 0;
-    a.sched = p8_tile_counter();
+    if (!p8_tile_counter_for(st, &a.sched))
+        MMGL_FAIL(MMGL_ERR_INVALID, "gemm8p: the dynamic tile schedule of this device is bound to another stream (one stream per device "
+                                    "while mmgl_gemm_set_tile_counter is in effect)");
     if (direct > 0) {
         a.total = direct;
         const int grid = direct < n_cu ? direct : n_cu;
@@ -830,6 +858,7 @@ extern "C" int mmgl_gemm_set_tile_counter(void* counter) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "mmgl_gemm_set_tile_counter: hipGetDevice: %s", hipGetErrorString(e));
+    g_tile_stream[dev & 63].store(P8_STREAM_UNBOUND, std::memory_order_release);       // the next launch binds the counters to its stream
     unsigned* old = g_tile_counter[dev & 63].exchange((unsigned*)counter, std::memory_order_acq_rel);
     g_tile_counters_set.fetch_add((counter != nullptr) - (old != nullptr), std::memory_order_relaxed);
     return MMGL_OK;

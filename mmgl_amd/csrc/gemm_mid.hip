@@ -114,8 +114,10 @@ __global__ __launch_bounds__(256, GM_OCC) void gemm_mid_kernel(MidArgs a) {
         const int k0 = t * GM_ROWB;                                      // bytes
 #pragma unroll
         for (int i = 0; i < DPS / 2; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + i * 4096), 16, xvoff, k0 + i * 4 * RPI * (int)ldxB, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + GM_TILEB + i * 4096), 16, wvoff, k0 + i * 4 * RPI * (int)ldwB, 0, 0);
+            // the row-block advance rides in the VECTOR offset: only voffset (+ the immediate) is range-checked against the descriptor,
+            // a scalar offset is not -- with it there, rows past M / N of a ragged tile were READ (up to 127 rows beyond the operand)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + i * 4096), 16, xvoff + (uint32_t)(i * 4 * RPI) * ldxB, k0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + GM_TILEB + i * 4096), 16, wvoff + (uint32_t)(i * 4 * RPI) * ldwB, k0, 0, 0);
         }
     };
 #pragma unroll

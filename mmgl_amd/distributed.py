@@ -42,11 +42,19 @@ def _grad_ready_order(named_params):
 class DataParallelEngine:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.01, bucket_mb: float = 256, tail_mb: float = 32, process_group=None, master_weights: Optional[bool] = None,
-                 fused: Optional[bool] = None, broadcast: bool = True, optimizer: str = "adamw"):
+                 fused: Optional[bool] = None, broadcast: bool = True, optimizer: str = "adamw", force_exchange: Optional[bool] = None):
+        import os
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        # `exchange`: do the hooks launch collectives?  Always with more than one rank; with ONE rank only when asked
+        # (force_exchange / MMGL_DDP_FORCE_EXCHANGE=1 and an initialised process group): a world_size-1 RCCL group runs the whole
+        # device-side path -- hook-launched async all-reduces on RCCL's stream, work.wait(), the dynamic GEMM tile schedule -- on
+        # the one GPU a test box has (tests/test_rccl_gpu.py, bench.py --force-exchange)
+        if force_exchange is None:
+            force_exchange = os.environ.get("MMGL_DDP_FORCE_EXCHANGE", "0") == "1"
+        self.exchange = self.world > 1 or (bool(force_exchange) and dist.is_initialized())
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.sync = True
@@ -67,8 +75,7 @@ class DataParallelEngine:
         if any(p.dtype != self.dtype or p.device != self.device for p in self.params):
             raise ValueError("DataParallelEngine: trainable parameters must share one dtype and device")
         self.fused = self.device.type == "cuda" if fused is None else fused
-        if self.world > 1 and self.device.type == "cuda":
-            import os
+        if self.exchange and self.device.type == "cuda":
             if os.environ.get("MMGL_GEMM_DYNAMIC", "1") != "0":
                 from . import ops
                 ops.gemm_dynamic_schedule(True, self.device)      # the GEMMs of the backward pass share the CUs with the all-reduces
@@ -87,15 +94,6 @@ class DataParallelEngine:
             self.flat_param[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.flat_param[o:o + p.numel()].view(p.shape)
             p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
-        if broadcast and self.world > 1:             # DDP's constructor broadcast of parameters AND buffers (run_generation.py:319)
-            dist.broadcast(self.flat_param, src=0, group=self.pg)
-            mine = {id(p) for p in self.params}
-            seen_t = set()
-            for t in list(model.parameters()) + list(model.buffers()):
-                if id(t) in mine or id(t) in seen_t or t.numel() == 0:
-                    continue
-                seen_t.add(id(t))
-                dist.broadcast(t.data, src=0, group=self.pg)      # frozen LM / encoders: one-off, ~3 GB at OPT-1.3B
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.master = self.flat_param.float() if master_weights else None
@@ -136,13 +134,27 @@ class DataParallelEngine:
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
         self.exchange_bytes = 0
-        # Collectives must be issued in the same order on every rank (RCCL matches them by issue order, not by buffer): the order
-        # is the order in which buckets fill, i.e. autograd's execution order of one graph -- identical by construction, and
-        # CHECKED on the first exchange of a run (and on every exchange under MMGL_DDP_CHECK_ORDER=1): see finish_backward
+        # Collectives must be issued in the same order on every rank (RCCL matches them by issue order, not by buffer).  The order
+        # is FIXED: bucket k is issued only after buckets 0..k-1 (a bucket that fills early waits for its predecessors; the flat
+        # buffer is laid out in grad-ready order, so in practice nothing waits), and the bucket LAYOUT -- the one thing that could
+        # still differ between ranks, if they built different models -- is compared across ranks here, before the first
+        # collective on gradient memory is ever issued.  A diagnostic after the fact (rounds 2-3) could only fire once RCCL had
+        # already matched mismatched all-reduces.
         self.launch_order: List[int] = []
-        self._order_checked = False
-        import os
-        self._always_check_order = os.environ.get("MMGL_DDP_CHECK_ORDER", "0") == "1"
+        self._next_launch = 0
+        if self.exchange:
+            self._check_bucket_layout()
+        if broadcast and self.exchange:              # DDP's constructor broadcast of parameters AND buffers (run_generation.py:319)
+            dist.broadcast(self.flat_param, src=0, group=self.pg)    # (after the layout check: a size mismatch must raise, not abort)
+            mine = {id(p) for p in self.params}
+            seen_t = set()
+            for t in list(model.parameters()) + list(model.buffers()):
+                if id(t) in mine or id(t) in seen_t or t.numel() == 0:
+                    continue
+                seen_t.add(id(t))
+                dist.broadcast(t.data, src=0, group=self.pg)      # frozen LM / encoders: one-off, ~3 GB at OPT-1.3B
+            if self.master is not None:
+                self.master.copy_(self.flat_param)
 
     # ---------------------------------------------------------------------------------- gradient exchange
     def _make_hook(self, i):
@@ -155,40 +167,46 @@ class DataParallelEngine:
                 param.grad = want.view(param.shape)
             b = self._bucket_of[i]
             b["pending"] -= 1
-            if b["pending"] == 0 and self.sync and self.world > 1:
-                self._launch(b)
+            if b["pending"] == 0 and self.sync and self.exchange:
+                self._launch_ready()
         return hook
 
+    def _launch_ready(self):
+        """Issue every filled bucket whose predecessors have all been issued: index order, on every rank."""
+        while self._next_launch < len(self.buckets) and self.buckets[self._next_launch]["pending"] == 0:
+            self._launch(self.buckets[self._next_launch])
+
     def _launch(self, b):
+        assert b["idx"] == self._next_launch, "bucket all-reduces are issued in index order"
         b["work"] = dist.all_reduce(self.flat_grad[b["start"]:b["end"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self.exchange_bytes += (b["end"] - b["start"]) * self.flat_grad.element_size()
         self.launch_order.append(b["idx"])
+        self._next_launch += 1
 
-    def _check_launch_order(self):
-        """Every rank must have issued its bucket all-reduces in the same order.  One tiny all-gather, after the exchange."""
-        n = len(self.buckets)
-        mine = torch.tensor((self.launch_order + [-1] * n)[:n], dtype=torch.int64, device=self.device)
+    def _check_bucket_layout(self):
+        """Every rank must cut the flat gradient into the same buckets (same model, same trainable set, same bucket_mb): one small
+        all-gather of the bucket boundaries at construction time."""
+        mine = torch.tensor([self.numel, len(self.buckets)] + [b["end"] for b in self.buckets], dtype=torch.int64, device=self.device)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(sizes, torch.tensor([mine.numel()], dtype=torch.int64, device=self.device), group=self.pg)
+        if any(int(t) != mine.numel() for t in sizes):
+            raise RuntimeError(f"DataParallelEngine: ranks built different numbers of gradient buckets: {[int(t) - 2 for t in sizes]}")
         both = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(both, mine, group=self.pg)
-        orders = [t.tolist() for t in both]
-        if any(o != orders[0] for o in orders[1:]):
-            raise RuntimeError(f"DataParallelEngine: bucket all-reduces were issued in different orders across ranks: {orders} "
-                               "(the ranks ran different autograd graphs: a parameter unused on one rank, data-dependent control flow)")
-        self._order_checked = True
+        layouts = [t.tolist() for t in both]
+        if any(l != layouts[0] for l in layouts[1:]):
+            raise RuntimeError(f"DataParallelEngine: the gradient buckets differ across ranks (different trainable sets?): {layouts}")
 
     def finish_backward(self):
         """Call after loss.backward(): waits for the bucket all-reduces (if this was a sync step) and re-arms the hooks.
         A parameter that received no gradient leaves its bucket open: launched here (find_unused_parameters=False is a
         contract of the reference, so this is the rare path)."""
-        if self.sync and self.world > 1:
-            for b in self.buckets:
-                if b["work"] is None:
-                    self._launch(b)
+        if self.sync and self.exchange:
+            for b in self.buckets[self._next_launch:]:
+                self._launch(b)
             for b in self.buckets:
                 b["work"].wait()
-            if not self._order_checked or self._always_check_order:
-                self._check_launch_order()
-        self.launch_order = []
+        self.last_launch_order, self.launch_order, self._next_launch = self.launch_order, [], 0
         for b in self.buckets:
             b["pending"], b["work"] = len(b["members"]), None
 

@@ -20,9 +20,9 @@ self-attention kernel of the LM layers with the attention mask as key mask, add+
 padded length -- CLIP texts are at most 77 tokens.
 
 Forward only, no autograd (the encoders are frozen, reference :922-934).  An architecture none of these cover
-(`supports()` is False: relative position embeddings, exotic activations) is an error at construction time unless the caller
-opts into the HF forward explicitly (`args.allow_hf_encoder_forward`); inputs the kernels cannot take (CPU tensors, a sequence
-whose first token is masked) raise.
+(`supports()` is False: relative position embeddings, exotic activations) is an error at construction time -- the product has
+no HuggingFace / library-GEMM forward to fall back to (HF forwards appear in tests only, as the thing compared against);
+inputs the kernels cannot take (CPU tensors, a sequence whose first token is masked) raise.
 """
 import math
 

@@ -772,35 +772,6 @@ def host_metadata(batch):
     return meta
 
 
-def encode_text_bucketed(text_model, ids, am, n_buckets=4, use_pooler_output=False):
-    """CLS / pooled output of a frozen text encoder over [n, L] right-padded sequences, WITHOUT computing the padding:
-    sequences are sorted by length and encoded in `n_buckets` groups, each truncated to its own longest member (rounded
-    up to 8).  Removing trailing pad keys leaves every softmax unchanged (their weight is exactly 0), so the result equals
-    the padded call up to summation order; the reference pads every neighbor to max_input_length (data.py:457), i.e. ~half
-    of the encoder FLOPs at WikiWeb2M's length spread.  One host sync (the lengths)."""
-    n, L = ids.shape
-    pick = (lambda o: o.pooler_output) if use_pooler_output else (lambda o: o.last_hidden_state[:, 0])
-    if n_buckets <= 1 or n < 2 * n_buckets or L < 64:
-        return pick(text_model(input_ids=ids, attention_mask=am))
-    lens = am.sum(1).clamp_min(1)
-    order = torch.argsort(lens)
-    lens_sorted = lens[order].cpu().tolist()              # host sync
-    out = None
-    start = 0
-    for bkt in range(n_buckets):
-        end = n if bkt == n_buckets - 1 else (n * (bkt + 1)) // n_buckets
-        if end <= start:
-            continue
-        Lb = min(L, (int(lens_sorted[end - 1]) + 7) // 8 * 8)
-        idx = order[start:end]
-        o = pick(text_model(input_ids=ids.index_select(0, idx)[:, :Lb].contiguous(), attention_mask=am.index_select(0, idx)[:, :Lb].contiguous()))
-        if out is None:
-            out = o.new_zeros(n, o.shape[-1])
-        out.index_copy_(0, idx, o)
-        start = end
-    return out
-
-
 class TextPooler(nn.Module):
     """CLS token -> Linear -> tanh (reference :879-893)."""
 
@@ -865,23 +836,16 @@ class CrossAttentionModel(nn.Module):
         # Padded neighbor slots (pos_id 0) are masked keys: they can influence neither the logits nor any gradient, so
         # the frozen encoders skip them (the reference encodes '' texts and all-zero images, data.py:444-454).
         self.skip_padded_neighbors = getattr(args, "skip_padded_neighbors", True)
-        self.text_length_buckets = getattr(args, "text_length_buckets", 4)     # 1 = encode everything padded to L (reference)
-        # packed (padding-free) HIP forward of the frozen encoders; the HF modules stay the owners of the weights
-        self.packed_encoders = getattr(args, "packed_encoders", True)
+        # packed (padding-free) HIP forward of the frozen encoders -- the only forward they have here; the HF modules stay the owners
+        # of the weights.  An encoder architecture none of the HIP forwards cover is an error, never a library-GEMM / SDPA forward.
         self._packed_text = PackedTextEncoder(self.text_model) if (self.text_model is not None and PackedTextEncoder.supports(self.text_model)) else None
         self._clip_text = ClipTextEncoder(self.text_model) if (self.text_model is not None and ClipTextEncoder.supports(self.text_model)) else None
         self._packed_visual = PackedVisionEncoder(self.visual_model) if (self.visual_model is not None and PackedVisionEncoder.supports(self.visual_model)) else None
-        # an encoder architecture none of the HIP forwards cover runs its HF forward (library GEMMs, SDPA) only when the caller asked
-        # for exactly that; silently measuring / training on a different code path is what this refuses
-        self.allow_hf_encoder_forward = bool(getattr(args, "allow_hf_encoder_forward", False)) or not self.packed_encoders
-        if not self.allow_hf_encoder_forward:
-            if self.text_model is not None and self._packed_text is None and self._clip_text is None:
-                raise ValueError(f"text_model {type(self.text_model).__name__}: no HIP forward for this architecture (RoBERTa/BERT-style "
-                                 "absolute-position encoders and CLIP's text tower are covered); set args.allow_hf_encoder_forward = True "
-                                 "to run the HuggingFace forward instead")
-            if self.visual_model is not None and self._packed_visual is None:
-                raise ValueError(f"visual_model {type(self.visual_model).__name__}: no HIP forward for this architecture (CLIP ViT is covered); "
-                                 "set args.allow_hf_encoder_forward = True to run the HuggingFace forward instead")
+        if self.text_model is not None and (self._clip_text if "clip" in args.text_model else self._packed_text) is None:
+            raise ValueError(f"text_model {type(self.text_model).__name__}: no HIP forward for this architecture (RoBERTa/BERT-style "
+                             "absolute-position encoders and CLIP's text tower are covered)")
+        if self.visual_model is not None and self._packed_visual is None:
+            raise ValueError(f"visual_model {type(self.visual_model).__name__}: no HIP forward for this architecture (CLIP ViT is covered)")
 
         if self.args.freeze_lm:
             print("Freezing the LM.")
@@ -932,13 +896,10 @@ class CrossAttentionModel(nn.Module):
         with torch.no_grad():
             if rows is not None:
                 ids, am = ids.index_select(0, rows), am.index_select(0, rows)
-            is_clip = "clip" in self.args.text_model
-            if self.packed_encoders and is_clip and self._clip_text is not None:
+            if "clip" in self.args.text_model:
                 enc = self._clip_text.pooled(ids, am)
-            elif self.packed_encoders and self._packed_text is not None and not is_clip:
+            else:
                 enc = self._packed_text.cls(ids, am, lens_host)
-            else:               # allow_hf_encoder_forward (or packed_encoders off): the HF module, length-bucketed
-                enc = encode_text_bucketed(self.text_model, ids, am, 1 if is_clip else self.text_length_buckets, use_pooler_output=is_clip)
             if rows is not None:
                 full = enc.new_zeros(batch_size * neighbor_num, enc.shape[-1])
                 enc = full.index_copy_(0, rows, enc)
@@ -967,10 +928,7 @@ class CrossAttentionModel(nn.Module):
                 pooled = pixel_values.new_zeros(0, hidden, dtype=next(self.visual_model.parameters()).dtype)
             else:
                 pv = pv.to(next(self.visual_model.parameters()).dtype)
-                if self.packed_encoders and self._packed_visual is not None:
-                    pooled = self._packed_visual.pooled(pv)
-                else:
-                    pooled = self.visual_model(pv).pooler_output
+                pooled = self._packed_visual.pooled(pv)
             if rows is not None:
                 pooled = pooled.new_zeros(batch_size * neighbor_num, hidden).index_copy_(0, rows, pooled)
         return self._project(pooled, self.visual_embeddings, self.visual_position_embeddings, pos_ids, batch_size, self.n_visual_tokens)

@@ -191,15 +191,13 @@ class SelfAttentionModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------ encoders
     def _packed(self, model, cls):
-        """Padding-free HIP forward of a frozen encoder (encoders.py), or None when it does not cover `model`."""
-        if not getattr(self.args, "packed_encoders", True) or model is None:
-            return None
+        """Padding-free HIP forward of a frozen encoder (encoders.py) -- the only forward it has here: an architecture `cls` does
+        not cover raises (no HuggingFace / library-GEMM forward in the product)."""
         cache = self.__dict__.setdefault("_packed_cache", {})
         if id(model) not in cache:
-            if not cls.supports(model) and not getattr(self.args, "allow_hf_encoder_forward", False):
-                raise ValueError(f"{type(model).__name__}: no HIP forward for this encoder architecture ({cls.__name__} does not cover it); "
-                                 "set args.allow_hf_encoder_forward = True to run the HuggingFace forward instead")
-            cache[id(model)] = cls(model) if cls.supports(model) else None
+            if not cls.supports(model):
+                raise ValueError(f"{type(model).__name__}: no HIP forward for this encoder architecture ({cls.__name__} does not cover it)")
+            cache[id(model)] = cls(model)
         return cache[id(model)]
 
     def _project(self, pooled, linear, pos_emb, pos_ids, batch_size, n_tokens):
@@ -212,10 +210,7 @@ class SelfAttentionModel(nn.Module):
         batch_size, neighbor_num, seq_len = input_ids.shape
         ids, am = input_ids.reshape(-1, seq_len), attention_mask.reshape(-1, seq_len)
         with torch.no_grad():
-            packed = self._packed(self.text_model, PackedTextEncoder)
-            cls = packed.cls(ids, am) if packed is not None else None
-            if cls is None:
-                cls = self.text_model(input_ids=ids, attention_mask=am).last_hidden_state[:, 0]
+            cls = self._packed(self.text_model, PackedTextEncoder).cls(ids, am)
         pooled = self.text_pooler(cls.unsqueeze(1))
         pos = getattr(self, "text_position_embeddings", None) if self.position_type != "none" else None
         return self._project(pooled, self.text_embeddings, pos, pos_ids, batch_size, self.n_text_tokens)
@@ -224,10 +219,7 @@ class SelfAttentionModel(nn.Module):
         batch_size, neighbor_num, pixel, width, height = pixel_values.shape
         with torch.no_grad():
             pv = pixel_values.reshape(-1, pixel, width, height).to(next(self.visual_model.parameters()).dtype)
-            packed = self._packed(self.visual_model, PackedVisionEncoder)
-            pooled = packed.pooled(pv) if packed is not None else None
-            if pooled is None:
-                pooled = self.visual_model(pv).pooler_output
+            pooled = self._packed(self.visual_model, PackedVisionEncoder).pooled(pv)
         pos = getattr(self, "visual_position_embeddings", None) if self.position_type != "none" else None
         return self._project(pooled, self.visual_embeddings, pos, pos_ids, batch_size, self.n_visual_tokens)
 

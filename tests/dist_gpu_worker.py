@@ -20,7 +20,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
-    os.environ["MMGL_DDP_CHECK_ORDER"] = "1"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("MMGL_DIST_BACKEND", "nccl")
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
@@ -38,8 +37,13 @@ def main():
         load_exact(model, fx.p)
     model = model.to(dev).train()
     # small buckets: several all-reduces per step, so that the launch-order check has something to compare
-    engine = DataParallelEngine(model, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01, bucket_mb=0.02, tail_mb=0.005)
+    # world == 1: the exchange is FORCED ON (a world_size-1 RCCL group on the one GPU of the box): hooks, async all-reduces on RCCL's
+    # stream, work.wait(), the dynamic GEMM tile schedule -- everything but the wire
+    engine = DataParallelEngine(model, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01, bucket_mb=0.02, tail_mb=0.005, force_exchange=True)
     assert len(engine.buckets) >= 3, len(engine.buckets)
+    assert engine.exchange
+    from mmgl_amd import _lib
+    assert _lib.lib().mmgl_gemm_get_tile_counter(), "the engine must switch the persistent GEMM to the dynamic tile schedule"
 
     def batch_of(r, step):
         g = torch.Generator().manual_seed(1000 * step + r)
@@ -49,12 +53,13 @@ def main():
         b["labels"] = b["input_ids"].clone()
         return {k: v.to(dev) for k, v in b.items()}
 
-    report = dict(world=world, backend=backend, buckets=len(engine.buckets), steps=[])
+    report = dict(world=world, backend=backend, buckets=len(engine.buckets), steps=[], launch_order=None)
     for step in range(2):
         # (a) the exchanged gradient
         engine.sync = True
         model(**batch_of(rank, step)).loss.backward()
         engine.finish_backward()
+        assert engine.last_launch_order == list(range(len(engine.buckets))), engine.last_launch_order
         got = engine.flat_grad.clone()
         # (b) the same sum without any exchange: every rank's batch, accumulated locally
         engine.zero_grad()
@@ -65,6 +70,8 @@ def main():
         want = engine.flat_grad.clone()
         err = ((got - want).abs().max() / want.abs().max().clamp_min(1e-12)).item()
         assert err < 2e-5, f"rank {rank} step {step}: exchanged gradient differs from the local sum: {err}"
+        if world == 1:                                 # one rank: the all-reduce is the identity, so the two runs must agree to the bit
+            assert torch.equal(got, want), "world_size 1: the exchanged gradient differs from the one computed without the exchange"
         engine.flat_grad.copy_(got)
         engine.sync = True
         engine.step()
@@ -78,6 +85,7 @@ def main():
     assert all(torch.equal(both[0], t) for t in both[1:]), "parameters diverged across ranks"
     report["params_equal"] = True
     report["exchange_bytes"] = engine.exchange_bytes
+    report["launch_order"] = engine.last_launch_order
     if rank == 0:
         print(json.dumps(report), flush=True)
     dist.barrier()

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(h, n), f"{n} declared in include/mmgl_hip.h but not exported by libmmgl_hip.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in mmgl_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ set(names)
-    assert _lib.lib().mmgl_version() >= 100
+    assert _lib.lib().mmgl_version() == _lib.ABI_VERSION      # a stale .so (older ABI) is refused at load
 
 
 def test_library_is_not_older_than_its_sources():

@@ -226,3 +226,63 @@ def test_bf16_gradient_sum_over_eight_ranks_error_bound():
     rel = float((got - exact).norm() / exact.norm())
     worst = float((got - exact).abs().max() / exact.abs().max())
     assert rel <= 2.0 ** -8 and worst <= world * 2.0 ** -9, (rel, worst)
+
+
+def _order_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mmgl_amd.distributed import DataParallelEngine
+    torch.manual_seed(0)
+    m = Toy()
+    eng = DataParallelEngine(m, lr=1e-2, bucket_mb=0, tail_mb=0, fused=False, force_exchange=True)
+    assert eng.exchange and len(eng.buckets) == len(eng.params) >= 4
+    # fire the hooks in REVERSE grad-ready order (what a rank with a different autograd schedule would do): the engine must
+    # still issue bucket 0 first, then 1, ... -- the all-reduces of a filled bucket wait for its predecessors
+    for p in eng.params:
+        p.grad.fill_(1.0)
+    seen = []
+    for i in reversed(range(len(eng.params))):
+        eng._make_hook(i)(eng.params[i])
+        seen.append(list(eng.launch_order))
+    assert seen[0] == [] and seen[-2] == [], seen              # nothing may go out before bucket 0 is full
+    assert seen[-1] == list(range(len(eng.buckets)))
+    eng.finish_backward()
+    assert eng.last_launch_order == list(range(len(eng.buckets)))
+    assert torch.equal(eng.flat_grad[:eng.params[0].numel()], torch.full((eng.params[0].numel(),), float(world)))
+    if rank == 0:
+        torch.save(dict(ok=True), out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_bucket_all_reduces_go_out_in_index_order_whatever_the_hook_order(tmp_path, world):
+    """ADVICE round 3: the order check ran after the collectives it was meant to protect.  Now the order is fixed by construction;
+    world = 1 with force_exchange is the configuration tests/test_rccl_gpu.py runs over RCCL."""
+    out = str(tmp_path / "ok.pt")
+    mp.spawn(_order_worker, nprocs=world, args=(world, _free_port(), out), join=True)
+    assert torch.load(out)["ok"]
+
+
+def _layout_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mmgl_amd.distributed import DataParallelEngine
+    torch.manual_seed(0)
+    m = Toy()
+    if rank == 1:
+        m.neighbor_layers[1].bias.requires_grad = False       # a different trainable set on one rank
+    try:
+        DataParallelEngine(m, lr=1e-2, bucket_mb=256, fused=False)
+        raised = False
+    except RuntimeError as e:
+        raised = "differ across ranks" in str(e) or "different numbers" in str(e)
+    torch.save(dict(raised=raised), f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_mismatched_bucket_layout_raises_at_construction(tmp_path):
+    out = str(tmp_path / "layout")
+    mp.spawn(_layout_worker, nprocs=2, args=(2, _free_port(), out), join=True)
+    assert torch.load(f"{out}.0")["raised"] and torch.load(f"{out}.1")["raised"]

@@ -241,5 +241,6 @@ def test_unsupported_encoder_architecture_raises_instead_of_running_hf():
     with pytest.raises(ValueError, match="no HIP forward"):
         CrossAttentionModel(mpt_args(context="all"), tokenizer=None, lm_config=tiny_opt_config(), text_config=rel, visual_config=tiny_clip_vision_config())
     args = mpt_args(context="all")
-    args.allow_hf_encoder_forward = True
-    CrossAttentionModel(args, tokenizer=None, lm_config=tiny_opt_config(), text_config=rel, visual_config=tiny_clip_vision_config())
+    args.allow_hf_encoder_forward = True            # round 3's opt-in is gone: there is no HF forward in the product to opt into
+    with pytest.raises(ValueError, match="no HIP forward"):
+        CrossAttentionModel(args, tokenizer=None, lm_config=tiny_opt_config(), text_config=rel, visual_config=tiny_clip_vision_config())

@@ -263,6 +263,69 @@ def test_dynamic_tile_schedule_is_bitwise_the_static_one(M, N, K, act, bias, res
     assert torch.equal(y0, y1) and torch.equal(y0, y2)
 
 
+@pytest.mark.parametrize("M", [8192, 12288, 16384, 20480, 24576])
+def test_dynamic_tile_schedule_one_to_three_rounds(M):
+    """every workgroup claimed three items before computing anything, so an output of 1 / 1.5 / 2 / 2.5 rounds of tiles
+    (256 / 384 / 512 / 640 tiles on 256 CUs) was computed by a fraction of the CUs: 3 tile times where the static schedule takes
+    1 / 2 / 2 / 3.  Up-front claims are capped at ceil(items / workgroups) now: bit-identical output, counters left at zero, and the
+    dynamic launch takes no longer than the static one (a gross check: 1.35x; the defect was 1.5x - 3x)."""
+    from mmgl_amd import ops
+    N = K = 2048
+    x, W, b, _, _ = _mk(M, N, K, seed=M, bias=True)
+    y0 = ops.gemm_nt(x, W, b, act=1)
+
+    def timed():
+        for _ in range(3):
+            ops.gemm_nt(x, W, b, act=1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            y = ops.gemm_nt(x, W, b, act=1)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 10, y
+
+    t_static, _ = timed()
+    ctr = ops.gemm_dynamic_schedule(True)
+    try:
+        t_dyn, y1 = timed()
+        assert int(ctr.abs().sum()) == 0, ctr.tolist()
+    finally:
+        ops.gemm_dynamic_schedule(False)
+    assert torch.equal(y0, y1)
+    print(f"M={M}: static {t_static * 1e3:.1f} us, dynamic {t_dyn * 1e3:.1f} us")
+    assert t_dyn < 1.35 * t_static, (t_static, t_dyn)
+
+
+def test_dynamic_tile_schedule_is_bound_to_one_stream():
+    """include/mmgl_hip.h: while a tile counter is set, the device's persistent-GEMM launches belong to ONE stream (the counters are
+    shared); a launch on a second stream is refused with MMGL_ERR_INVALID (-> ValueError) instead of corrupting both schedules, and
+    setting the counter again releases the binding."""
+    from mmgl_amd import ops
+    x, W, b, _, _ = _mk(8192, 2048, 2048, seed=5, bias=True)
+    y0 = ops.gemm_nt(x, W, b)
+    side = torch.cuda.Stream()
+    ops.gemm_dynamic_schedule(True)
+    try:
+        y1 = ops.gemm_nt(x, W, b)                    # binds the counters to the current stream
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            with pytest.raises(ValueError, match="bound to another stream"):
+                ops.gemm_nt(x, W, b)
+        y2 = ops.gemm_nt(x, W, b)                    # the bound stream keeps working
+        ops.gemm_dynamic_schedule(True)              # set again: binding released
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            y3 = ops.gemm_nt(x, W, b)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_dynamic_schedule(False)
+    with torch.cuda.stream(side):                    # static schedule: any stream
+        y4 = ops.gemm_nt(x, W, b)
+    torch.cuda.synchronize()
+    assert all(torch.equal(y0, y) for y in (y1, y2, y3, y4))
+
+
 def test_dynamic_tile_schedule_reaches_the_backward_thread():
     """The GEMMs that overlap the gradient all-reduce are the BACKWARD ones, and autograd launches those from its own device thread:
     the schedule set from the main thread must be what a launch from another thread sees (a thread-local setting left exactly those

@@ -146,29 +146,6 @@ def test_value_errors_match_reference():
                             visual_config=tiny_clip_vision_config())
 
 
-def test_bucketed_text_encoding_equals_padded():
-    """Length-bucketed (padding-free) encoding of the frozen text encoder == the padded call (reference behaviour)."""
-    from transformers import RobertaConfig, RobertaModel
-    from mmgl_amd.model.modelling_cross_attention import encode_text_bucketed
-    torch.manual_seed(0)
-    cfg = RobertaConfig(vocab_size=200, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
-                        max_position_embeddings=260, pad_token_id=1, type_vocab_size=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    enc = RobertaModel(cfg, add_pooling_layer=False).cuda().eval()
-    n, L = 37, 256
-    g = torch.Generator().manual_seed(1)
-    ids = torch.randint(3, 200, (n, L), generator=g)
-    am = torch.ones(n, L, dtype=torch.long)
-    for i in range(n):
-        ln = int(torch.randint(2, L + 1, (1,), generator=g))
-        ids[i, ln:] = 1
-        am[i, ln:] = 0
-    ids, am = ids.cuda(), am.cuda()
-    with torch.no_grad():
-        want = enc(input_ids=ids, attention_mask=am).last_hidden_state[:, 0]
-        got = encode_text_bucketed(enc, ids, am, n_buckets=4)
-    assert_close(got, want, 1e-5, "bucketed CLS")
-
-
 def test_initialize_lm_from_pretrained_round_trip(tmp_path):
     """The HF loading path (reference model/modelling_cross_attention.py:951-976): a random OPT is written with
     save_pretrained, `initialize_lm` reads it back through AutoConfig / AutoModelForCausalLM.from_pretrained and copies it

@@ -49,6 +49,32 @@ def test_two_ranks_on_one_gpu_engine_with_device_tensors():
     assert all(s["grad_rel_err"] < 2e-5 for s in rep["steps"])
 
 
+def test_one_rank_engine_over_rccl_with_the_exchange_forced_on():
+    """RCCL on the GPU this box has: a world_size-1 `nccl` process group on cuda:0 with the engine's exchange forced on -- the
+    post-accumulate-grad hooks issue `dist.all_reduce(async_op=True)` per bucket (index order) on RCCL's stream during backward,
+    `finish_backward` waits on the works, the persistent GEMM runs on its dynamic tile schedule, fused AdamW steps the flat buffers.
+    With one rank the sum is the identity: the worker asserts the exchanged gradient is BIT-identical to the same step without the
+    exchange, both steps (reference DDP wiring: run_generation.py:283, 317-319, 485)."""
+    rep = _run_worker("nccl", nproc=1)
+    assert rep["world"] == 1 and rep["backend"] == "nccl" and rep["params_equal"] and rep["buckets"] >= 3
+    assert rep["exchange_bytes"] > 0 and rep["launch_order"] == list(range(rep["buckets"]))
+    assert all(s["grad_rel_err"] == 0.0 for s in rep["steps"])
+
+
+def test_bench_one_rank_over_rccl_reports_the_exchange():
+    """`bench.py --force-exchange`: the same forced world_size-1 RCCL exchange inside the bench step, with the `exchange` block
+    (allreduce_ms_alone, step_ms_without_exchange) in the line."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-exchange", "--config", "opt-125m", "--batch", "4",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing", "--ref-batch", "0"], capture_output=True,
+                       text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    ex = line["exchange"]
+    assert line["n_gpus"] == 1 and ex["rccl_ranks"] == 1 and ex["backend"] == "nccl" and ex["forced"]
+    assert ex["exchange_bytes_per_step_per_gpu"] > 0 and ex["allreduce_ms_alone"] >= 0 and ex["step_ms_without_exchange"] > 0
+
+
 @pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs >= 2 GPUs")
 def test_two_ranks_engine_over_rccl():
     rep = _run_worker("nccl")
