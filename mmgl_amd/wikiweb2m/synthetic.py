@@ -54,3 +54,44 @@ def synthetic_tokenizer(extra_words=()):
     tok.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.WhitespaceSplit(), pre_tokenizers.Punctuation()])
     tok.post_processor = processors.TemplateProcessing(single="</s> $A", special_tokens=[("</s>", 2)])
     return PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="</s>", eos_token="</s>", pad_token="<pad>", unk_token="<unk>")
+
+
+def synthetic_images(df: pd.DataFrame, image_dir: str, seed: int = 0, keep: float = 0.55):
+    """Image files for `synthetic_pages` in the layout the reference reads (`{page}_{section}_{idx}.{ext}`, ext taken from the image
+    URL: wikiweb2m/data.py:132-136, preprocess_data.py:201-202).  A random subset of the (section, image) slots gets a small
+    random RGB picture -- PNG bytes under the URL's `.jpg` name (PIL detects the format from the content; lossless, so the decoded
+    pixels do not depend on the JPEG library) -- and every seventh written slot holds garbage instead, which exercises the reference's
+    `except: continue` (the next image of that section is tried).  Returns {file name: "image" | "corrupt"}."""
+    import os
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    os.makedirs(image_dir, exist_ok=True)
+    written = {}
+    for r in df.itertuples():
+        ns = len(r.section_title)
+        urls = r.image_url.reshape(ns, -1)
+        for s in range(ns):
+            for i in range(urls.shape[1]):
+                if rng.rand() >= keep:
+                    continue
+                ext = os.path.splitext(urls[s][i].decode())[1][1:]
+                name = f"{int(r.page_id)}_{s}_{i}.{ext}"
+                path = os.path.join(image_dir, name)
+                if len(written) % 7 == 3:
+                    with open(path, "wb") as f:
+                        f.write(b"not an image")
+                    written[name] = "corrupt"
+                    continue
+                h, w = int(rng.randint(8, 40)), int(rng.randint(8, 40))
+                Image.fromarray(rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)).save(path, format="PNG")
+                written[name] = "image"
+    return written
+
+
+def synthetic_pixel_values(img):
+    """Offline stand-in for `AutoFeatureExtractor(...)(img.convert('RGB')).pixel_values[0]` (language_modelling/utils.py:21-23):
+    RGB, nearest-neighbour resize to 224 x 224, [0, 1] floats, channels first -- deterministic, no pretrained preprocessor config."""
+    import torch
+    from PIL import Image
+    a = np.asarray(img.convert("RGB").resize((224, 224), Image.NEAREST), dtype=np.float32) / 255.0
+    return torch.from_numpy(a).permute(2, 0, 1).contiguous()

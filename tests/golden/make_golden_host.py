@@ -69,6 +69,58 @@ def golden_data():
                 flat[f"{case}/{i}/{k}"] = v.numpy()
     np.savez_compressed(os.path.join(HERE, "g6_data.npz"), **flat)
     print(f"wrote g6_data.npz: {len(flat)} arrays, {os.path.getsize(os.path.join(HERE, 'g6_data.npz'))/1024:.1f} KiB")
+    golden_data_with_images(ref, df, ids, tok)
+
+
+IMAGE_CASES = {
+    # the with-image slot order of get_embedding_item (wikiweb2m/data.py:363-420) and the raw-mode image splicing (:158-240)
+    "emb_all_dec_img": dict(),
+    "emb_all_dec_wide_img": dict(max_text_neighbors=11, max_image_neighbors=5, max_input_length=48),
+    "emb_all_dec_tight_img": dict(max_text_neighbors=3, max_image_neighbors=1),
+    "emb_all_encdec_img": dict(decoder_only=False),
+    "raw_section_all_img": dict(neighbor_mode="raw", context="section_all"),
+    "raw_all_img": dict(neighbor_mode="raw", context="all", max_input_length=96),
+    "raw_all_encdec_img": dict(neighbor_mode="raw", context="all", max_input_length=96, decoder_only=False),
+}
+
+
+def golden_data_with_images(ref, df, ids, tok):
+    """G6 with image neighbors: the reference checks `self.image_path/{page}_{section}_{idx}.{ext}` and then opens
+    `./wikiweb2m/raw/images/...` relative to the working directory (data.py:136-140) -- so the synthetic image files go into a temp
+    `wikiweb2m/raw/images`, the process chdir()s next to it, `image_path` points at it, and the (absent) HF feature extractor is
+    stubbed by mmgl_amd.wikiweb2m.synthetic.synthetic_pixel_values.  Pixel tensors are stored as float16-exact values
+    (k / 255 is not, so they are compared through their uint8 source: stored as uint8 * 1, see below)."""
+    import tempfile
+    from mmgl_amd.wikiweb2m.synthetic import synthetic_images, synthetic_pixel_values
+    sys.modules["language_modelling.utils"].get_pixel_values_for_model = lambda fe, img: synthetic_pixel_values(img)
+    ref.utils.get_pixel_values_for_model = lambda fe, img: synthetic_pixel_values(img)
+    flat, cwd = {}, os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        image_dir = os.path.join(tmp, "wikiweb2m", "raw", "images")
+        written = synthetic_images(df, image_dir, seed=11)
+        os.chdir(tmp)
+        try:
+            n_img = 0
+            for case, kw in IMAGE_CASES.items():
+                ds = ref.WikiWeb2M(data_args(**kw), df, ids, tok, None)
+                ds.image_path = image_dir
+                ds.visual_feature_extractor = object()           # the reference only sets it when given a model name (:62-63)
+                for i in range(len(ids)):
+                    item = ds[i]
+                    for k, v in item.items():
+                        a = v.numpy()
+                        if a.dtype == np.float32 and a.ndim == 4:        # pixel stacks: k / 255 floats -> exact uint8 (4x smaller fixture)
+                            q = np.rint(a * 255.0)
+                            assert np.array_equal((q / 255.0).astype(np.float32), a)
+                            a = q.astype(np.uint8)
+                            n_img += int((a.reshape(a.shape[0], -1).max(1) > 0).sum())
+                        flat[f"{case}/{i}/{k}"] = a
+        finally:
+            os.chdir(cwd)
+    assert n_img > 20, n_img
+    np.savez_compressed(os.path.join(HERE, "g6_data_images.npz"), **flat)
+    print(f"wrote g6_data_images.npz: {len(flat)} arrays, {n_img} non-blank image slots, {sum(v == 'corrupt' for v in written.values())} corrupt "
+          f"files of {len(written)}, {os.path.getsize(os.path.join(HERE, 'g6_data_images.npz'))/1024:.1f} KiB")
 
 
 def golden_self_attention():

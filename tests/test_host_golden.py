@@ -47,6 +47,49 @@ def test_g6_dataset_items_bit_exact(case):
             assert np.array_equal(got, v), (case, i, k)
 
 
+IMAGE_CASES = {
+    "emb_all_dec_img": dict(),
+    "emb_all_dec_wide_img": dict(max_text_neighbors=11, max_image_neighbors=5, max_input_length=48),
+    "emb_all_dec_tight_img": dict(max_text_neighbors=3, max_image_neighbors=1),
+    "emb_all_encdec_img": dict(decoder_only=False),
+    "raw_section_all_img": dict(neighbor_mode="raw", context="section_all"),
+    "raw_all_img": dict(neighbor_mode="raw", context="all", max_input_length=96),
+    "raw_all_encdec_img": dict(neighbor_mode="raw", context="all", max_input_length=96, decoder_only=False),
+}
+
+
+@pytest.mark.parametrize("case", sorted(IMAGE_CASES))
+def test_g6_dataset_items_with_image_neighbors_bit_exact(case, tmp_path):
+    """The WITH-IMAGE branch of the collate against the reference itself (wikiweb2m/data.py:118-144, 363-420; raw modes :158-240):
+    slot order section image -> caption -> other sections' text / image / caption under the text / image caps, a corrupt file skipped
+    in favour of the section's next image, blank pixels + position 0 for padding slots.  Fixture: tests/golden/make_golden_host.py ran
+    the reference's WikiWeb2M over the same synthetic pages and image files (temp image dir + chdir, stubbed feature extractor)."""
+    from mmgl_amd.wikiweb2m import WikiWeb2M
+    from mmgl_amd.wikiweb2m.synthetic import (synthetic_id_list, synthetic_images, synthetic_pages, synthetic_pixel_values,
+                                             synthetic_tokenizer)
+    z = np.load(os.path.join(GOLDEN, "g6_data_images.npz"))
+    df = synthetic_pages(4, seed=3)
+    ids = synthetic_id_list(df)
+    written = synthetic_images(df, str(tmp_path / "images"), seed=11)
+    assert "corrupt" in written.values() and "image" in written.values()
+    ds = WikiWeb2M(data_args(**IMAGE_CASES[case]), df, ids, synthetic_tokenizer(), synthetic_pixel_values, image_dir=str(tmp_path / "images"))
+    ds.visual_feature_extractor = synthetic_pixel_values          # (the constructor only keeps it for context section_all / all, like the reference)
+    n_img = 0
+    for i in range(len(ids)):
+        item = ds[i]
+        want = {k.split("/", 2)[2]: z[k] for k in z.files if k.startswith(f"{case}/{i}/")}
+        assert set(item) == set(want), (case, i, set(item) ^ set(want))
+        for k, v in want.items():
+            got = item[k].numpy()
+            if v.dtype == np.uint8:                                # pixel stacks are stored as the exact uint8 they came from
+                assert got.dtype == np.float32
+                v = (v.astype(np.float32) / 255.0).astype(np.float32)
+                n_img += int((v.reshape(v.shape[0], -1).max(1) > 0).sum())
+            assert got.dtype == v.dtype and got.shape == v.shape, (case, i, k, got.dtype, v.dtype, got.shape, v.shape)
+            assert np.array_equal(got, v), (case, i, k)
+    assert n_img > 0, "the fixture case holds no image neighbor at all"
+
+
 def test_dataset_default_collate_stacks():
     from mmgl_amd.wikiweb2m import WikiWeb2M
     from mmgl_amd.wikiweb2m.synthetic import synthetic_id_list, synthetic_pages, synthetic_tokenizer

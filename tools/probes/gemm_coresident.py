@@ -17,7 +17,12 @@ occ.occupier_spin.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
 
 
 def main():
-    M, N, K = 40960, 2048, 2048
+    # 5 rounds of tiles (the round-3 measurement), then the few-round outputs of ADVICE round 3: 1 / 1.5 / 2 / 2.5 rounds
+    for M in [int(a) for a in sys.argv[1:]] or [40960, 8192, 12288, 16384, 20480]:
+        one(M, 2048, 2048)
+
+
+def one(M, N, K):
     x = torch.randn(M, K, device="cuda").bfloat16()
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
     y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
