@@ -140,15 +140,39 @@ def synthetic_batch(B, cfg, seed, device, Ln=512):
     return batch, valid_keys
 
 
-def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1, repeats=3):
-    """Time the CPU oracle on the same step (frozen encoders fwd, LM fwd+bwd w.r.t. the trainable set) on a bounded sample:
-    one warm-up, then the median of `repeats` runs of `n_samples` sample(s) each.  fp32, host cores.  Returns the JSON object
-    for the bench line."""
-    from oracle import lm_ref, wrapper_ref
+def _cpu_threads():
     # threads: torch/MKL fp32 GEMM peaks at ~32 threads on the GPU box's 2 x 64-core EPYC 9575F and collapses beyond
-    # (tools/probes/cpu_threads.py: 1.44 TFLOP/s @32, 0.64 @64, 0.07 @256) -> use min(32, cpu_count)
-    cores = min(32, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
+    # (tools/probes/cpu_threads.py: 1.44 TFLOP/s @32, 0.64 @64, 0.07 @256) -> min(32, cpu_count) threads, BOTH numbers reported
+    return min(32, os.cpu_count() or 1)
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _median_time(fn, warmups, iters):
+    for _ in range(warmups):
+        fn()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], ts
+
+
+def _cpu_step(model, cfg, lm_cfg, batch, n_samples):
+    """closure running the CPU oracle's train step (frozen encoders fwd, LM fwd + bwd w.r.t. the trainable set) on `n_samples`
+    samples of `batch`; returns the loss"""
+    from oracle import lm_ref, wrapper_ref
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     trainable = [k for k, p in model.named_parameters() if p.requires_grad]
     for k in trainable:
@@ -163,42 +187,142 @@ def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1, repeats=3):
     def once():
         for k in trainable:
             sd[k].grad = None
-        t0 = time.time()
         with torch.no_grad():
             L = b["neighbor_input_ids"].shape[-1]
             tl = text_model(input_ids=b["neighbor_input_ids"].reshape(-1, L), attention_mask=b["neighbor_attention_mask"].reshape(-1, L)).last_hidden_state
             vp = visual_model(b["neighbor_images"].reshape(-1, 3, 224, 224)).pooler_output
         logits, loss = wrapper_ref.cross_attention_model_forward(sd, ocfg, b, tl, vp, "all", 4)
         loss.backward()
-        return time.time() - t0, float(loss.detach())
+        return float(loss.detach())
+    return once
 
-    once()                                              # warm-up (thread pool, allocator)
-    runs = sorted(once() for _ in range(repeats))
-    dt, loss = runs[len(runs) // 2]
+
+def cpu_protocol(cores):
+    """BASELINE.md section 3, items (i)-(iv), on the host cores with the CPU oracle (fp32): attention core fwd and fwd + bwd, one gated
+    cross-attention layer fwd + bwd, the 4-layer gated stack at OPT-1.3B dims, the full train step at OPT-125m dims (config 2).
+    Median of 5 after 2 warm-ups each; B = 2, T = 640, S = 64 (40 valid keys in sample 0), seed 1234; FLOPs = SURVEY.md 8(d)."""
+    from oracle import lm_ref
+    B, T, S, d, H, ffn = 2, 640, 64, 2048, 32, 8192
+    g = torch.Generator().manual_seed(1234)
+    rn = lambda *sh, std=1.0: torch.randn(*sh, generator=g) * std
+    valid = torch.ones(B, S, dtype=torch.long)
+    valid[0, 40:] = 0
+    s_valid = [40, 64]
+    add_mask = lm_ref.expand_mask(valid, torch.float32, T)
+    ocfg = lm_ref.LMConfig(vocab_size=50272, hidden_size=d, num_attention_heads=H, ffn_dim=ffn, num_hidden_layers=24, word_embed_proj_dim=d,
+                           neighbor_layer_wise=6)
+
+    def layer_params(pre):
+        p = {}
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            p[f"{pre}self_attn.{n}.weight"], p[f"{pre}self_attn.{n}.bias"] = rn(d, d, std=0.02), rn(d, std=0.02)
+        p[pre + "fc1.weight"], p[pre + "fc1.bias"] = rn(ffn, d, std=0.02), rn(ffn, std=0.02)
+        p[pre + "fc2.weight"], p[pre + "fc2.bias"] = rn(d, ffn, std=0.02), rn(d, std=0.02)
+        for n in ("self_attn_layer_norm", "final_layer_norm"):
+            p[f"{pre}{n}.weight"], p[f"{pre}{n}.bias"] = torch.ones(d), torch.zeros(d)
+        p[pre + "gating1"], p[pre + "gating2"] = torch.tensor([0.5]), torch.tensor([0.5])
+        for v in p.values():
+            v.requires_grad_()
+        return p
+
+    core_flops = sum(4.0 * T * sv * d for sv in s_valid)
+    block_flops = sum(4.0 * T * d * d + 4.0 * sv * d * d for sv in s_valid) + core_flops
+    layer_flops = block_flops + B * 4.0 * T * d * ffn
+    q, k, v = rn(B, T, d).requires_grad_(), rn(B, S, d).requires_grad_(), rn(B, S, d).requires_grad_()
+    hidden, ne = rn(B, T, d), rn(B, S, d)
+    out = {}
+
+    def rec(name, fn, flops, samples):
+        med, ts = _median_time(fn, 2, 5)
+        out[name] = {"ms": round(med * 1e3, 3), "gflops": round(flops / med / 1e9, 1), "samples_per_s": round(samples / med, 3),
+                     "runs_ms": [round(t * 1e3, 2) for t in ts]}
+
+    def core_fwd():
+        with torch.no_grad():
+            lm_ref.attention_core(q, k, v, add_mask, H)
+
+    def core_fwd_bwd():
+        for t in (q, k, v):
+            t.grad = None
+        lm_ref.attention_core(q, k, v, add_mask, H).sum().backward()
+
+    rec("attention_core_fwd", core_fwd, core_flops, B)
+    rec("attention_core_fwd_bwd", core_fwd_bwd, 3 * core_flops, B)
+    layers = [layer_params(f"l{i}.") for i in range(4)]
+
+    def stack(n):
+        def fn():
+            h = hidden
+            for i in range(n):
+                for t in layers[i].values():
+                    t.grad = None
+                h = lm_ref.decoder_layer(layers[i], f"l{i}.", h, None, ocfg, ne, add_mask, cross=True)
+            h.sum().backward()
+        return fn
+
+    rec("gated_layer_fwd_bwd", stack(1), 3 * layer_flops, B)
+    rec("gated_stack4_fwd_bwd", stack(4), 4 * 3 * layer_flops, B)
+    del layers
+
+    # (iv) the full train step at config 2's dimensions (OPT-125m, 2 + 2 neighbors), 2 samples
+    from mmgl_amd.model import CrossAttentionModel
+    cfg2 = CONFIGS["opt-125m"]
+    lm2, txt2, vis2 = hf_configs(cfg2)
+    torch.manual_seed(1234)
+    with torch.device("cpu"):
+        m2 = CrossAttentionModel(make_args(cfg2), tokenizer=None, lm_config=lm2, text_config=txt2, visual_config=vis2)
+    with torch.no_grad():
+        for n_, p_ in m2.named_parameters():
+            if n_.endswith("gating1") or n_.endswith("gating2"):
+                p_.fill_(0.5)
+    b2, _ = synthetic_batch(2, cfg2, seed=1234, device=torch.device("cpu"))
+    step2 = _cpu_step(m2, cfg2, lm2, b2, 2)
+    med, ts = _median_time(step2, 2, 5)
+    out["config2_full_step"] = {"ms": round(med * 1e3, 1), "samples_per_s": round(2 / med, 3), "runs_ms": [round(t * 1e3, 1) for t in ts],
+                                "what": "opt-125m flamingo, 2+2 neighbors, T=640: frozen encoders fwd + LM fwd + bwd, 2 samples"}
+    out["protocol"] = f"BASELINE.md section 3: fp32 CPU oracle, B=2, T=640, S=64 (40 / 64 valid keys), d=2048, H=32, ffn=8192; median of 5 after 2 warm-ups; {cores} threads"
+    return out
+
+
+def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1, repeats=3, protocol=True):
+    """The CPU oracle on the host cores, same bench run (kind "port"; the reference's Python does not travel).  `value`: the bench's own
+    workload -- config 3's train step (frozen encoders fwd, LM fwd + bwd w.r.t. the trainable set) on a bounded sample: one warm-up,
+    then the median of `repeats` runs of `n_samples` sample(s) (6 s each: the section-3 count of 2 + 5 would be 40 s).  `section3`:
+    BASELINE.md section 3's items (i)-(iv) at their own sizes, median of 5 after 2 warm-ups.  fp32."""
+    cores = _cpu_threads()
+    torch.set_num_threads(cores)
+    once = _cpu_step(model, cfg, lm_cfg, batch, n_samples)
+    loss = once()                                       # warm-up (thread pool, allocator)
+    dt, runs = _median_time(once, 0, repeats)
     model.text_model.to(batch["input_ids"].device)
     model.visual_model.to(batch["input_ids"].device)
-    return dict(value=n_samples / dt, unit="samples/s", cores=cores, kind="port", seconds=round(dt, 2),
-                runs_s=[round(r[0], 2) for r in runs],
-                sample=f"median of {repeats} runs (after 1 warm-up) of {n_samples} sample(s) of the same synthetic batch: frozen encoders fwd + LM "
-                       f"fwd + bwd (no optimizer step), fp32 torch oracle (oracle/), {cores} threads", loss=loss)
+    out = dict(value=n_samples / dt, unit="samples/s", cores=cores, cpu_count=os.cpu_count(), cpu_model=_cpu_model(), kind="port",
+               seconds=round(dt, 2), runs_s=[round(r, 2) for r in runs],
+               sample=f"median of {repeats} runs (after 1 warm-up) of {n_samples} sample(s) of the same synthetic batch: frozen encoders fwd + LM "
+                      f"fwd + bwd (no optimizer step), fp32 torch oracle (oracle/), {cores} threads of {os.cpu_count()} logical CPUs "
+                      f"(torch's fp32 GEMM collapses beyond 32 threads on this host class)", loss=loss)
+    if protocol:
+        out["section3"] = cpu_protocol(cores)
+    return out
 
 
 def pmc_traffic(B, lm_cfg, cfg, dtype):
     """HBM bytes per launch of xattn_fwd_kernel from the committed PMC collection (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate passes, gfx950 x2 fetch correction applied: profiles/r<round>_pmc_xattn_*.json) when it was taken at this exact
-    shape; None otherwise -- PMC counters cannot be read from inside this process."""
-    for rnd in ("r3", "r2", "r1"):                           # the latest round's collection first
-        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_xattn_B{B}_{dtype}.json")
+    shape, and the file it came from; (None, None) otherwise -- PMC counters cannot be read from inside this process, so `traffic` is
+    a committed measurement of the same kernel at the same shape, NOT a counter of this run (`traffic_source` says which file)."""
+    for rnd in ("r4", "r3", "r2", "r1"):                     # the latest round's collection first
+        rel = os.path.join("profiles", f"{rnd}_pmc_xattn_B{B}_{dtype}.json")
         try:
-            with open(path) as f:
+            with open(os.path.join(ROOT, rel)) as f:
                 d = json.load(f)
             c = d["config"]
             if (c["B"], c["H"], c["S"], c["D"]) == (B, lm_cfg.num_attention_heads, (cfg["nt"] + cfg["ni"]) * 4,
                                                    lm_cfg.hidden_size // lm_cfg.num_attention_heads) and c["T"] == 640:
-                return d["kernels"]["xattn_fwd_kernel"]["hbm_bytes_per_launch"]
+                return d["kernels"]["xattn_fwd_kernel"]["hbm_bytes_per_launch"], rel
         except (OSError, KeyError, ValueError):
             pass
-    return None
+    return None, None
 
 
 def main():
@@ -257,8 +381,8 @@ def main():
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                                **(dict(device_id=device) if backend == "nccl" else {}))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
+        dist.init_process_group(backend, rank=0, world_size=1, **(dict(device_id=device) if backend == "nccl" else {}))
     comm = world > 1 or forced                        # collectives are issued (RCCL) -- with one rank only under --force-exchange
 
     from mmgl_amd import _lib
@@ -442,12 +566,13 @@ def main():
                                     "algorithmic_flops_per_launch": x["flops"] / x["calls"]}
             elif x:
                 alg = sum(2.0 * T * d * esize + 2.0 * sv * d * esize for sv in valid_keys)     # bytes per launch
+                traffic, traffic_src = pmc_traffic(args.batch, lm_cfg, cfg, args.dtype)
                 flops = sum(4.0 * T * sv * d for sv in valid_keys)
                 sec = x["ms_avg"] * 1e-3
                 gbs = alg / sec / 1e9
                 line["roofline"] = {"kernel": "xattn_fwd_kernel (mmgl_xattn_fwd)", "bound": "hbm", "achieved": round(gbs, 1),
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                    "traffic": pmc_traffic(args.batch, lm_cfg, cfg, args.dtype),
+                                    "traffic": traffic, "traffic_source": traffic_src,
                                     "us_per_launch": round(x["ms_avg"] * 1e3, 2), "launches": x["calls"],
                                     "algorithmic_bytes_per_launch": alg, "tflops": round(flops / sec / 1e12, 2),
                                     "frac_of_bf16_mfma_peak": round(flops / sec / 1e12 / MFMA_BF16_PEAK_TF, 4)}
@@ -487,9 +612,19 @@ def main():
             line["exchange"] = exchange
         if world == 1 and not args.no_cpu_baseline and cfg["kind"] == "flamingo":
             line["cpu_baseline"] = cpu_baseline(model, cfg, lm_cfg, batch, args.cpu_samples)
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
     if comm:
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL writes its version banner to the C stdout of every rank (buffered: it used to land AFTER the JSON line when stdout is
+        # a file).  Tear the communicator down first, flush the C streams, and only then print the one JSON line -- the last line.
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -176,137 +176,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ X, c
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Large-shape forward GEMM (bf16, K % 64 == 0): 256x256 block tile, 8 waves as 4 (W rows) x 2 (X rows), each wave
-// 64x128 = 4x8 MFMA tiles, one workgroup per CU (128 KiB of LDS: two K-tile buffers).  Against the 128x128 kernel above: a
-// wave reads 12 KiB of fragments per 32 MFMAs instead of 8 KiB per 16, a K tile keeps each SIMD in MFMAs for ~1000 cycles
-// per wave between barriers (two waves per SIMD cover each other's LDS waits), and the LDS-DMA of tile kt+1 is issued
-// a whole tile ahead.  Same XOR-swizzled 128-byte LDS rows, same epilogue.
-#ifndef MMGL_TILE_GROUPED
-#define MMGL_TILE_GROUPED 1
-#endif
-constexpr int BT = 256;
-constexpr int BIG_TILE_BYTES = BT * ROWB;              // 32 KiB per operand per buffer
-
-template <int ACT>
-__global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
-                                                            bf16* __restrict__ Y, const bf16* __restrict__ bias, int M, int N,
-                                                            int K, float scale, int accumulate, int tiles_m, int tiles_n,
-                                                            const bf16* __restrict__ zmask) {
-    typedef bf16 T;
-    typedef GT<T> G;
-    typedef bf16x8 v8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sX = smem;                           // [2][BIG_TILE_BYTES]
-    char* sW = smem + 2 * BIG_TILE_BYTES;      // [2][BIG_TILE_BYTES]
-    const int vid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    int tm, tn;
-    if (MMGL_TILE_GROUPED) grouped_tile(vid, tiles_m, tiles_n, tm, tn);
-    else { tn = vid / tiles_m; tm = vid % tiles_m; }
-    const int m0 = tm * BT, n0 = tn * BT;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x = lane & 15, g = lane >> 4;
-    const int wn = wave >> 1, wm = wave & 1;           // wave tile: W rows wn*64 .. +63 (4 blocks), X rows wm*128 .. +127 (8 blocks)
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = vzero<f32x4>();
-
-    const int nk = K / G::BK;
-    auto glds_tile = [&](int kt, int buf) {
-        const int k0 = kt * G::BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rbase = (i * 8 + wave) * 8;
-            const int row = rbase + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
-            const T* gx = X + (size_t)min(m0 + row, M - 1) * K + k0 + c * G::VN;
-            const T* gw = W + (size_t)min(n0 + row, N - 1) * K + k0 + c * G::VN;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gx,
-                                             (__attribute__((address_space(3))) void*)(sX + buf * BIG_TILE_BYTES + rbase * ROWB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,
-                                             (__attribute__((address_space(3))) void*)(sW + buf * BIG_TILE_BYTES + rbase * ROWB), 16, 0, 0);
-        }
-    };
-    // Software pipeline: a K tile is two groups of 32 MFMAs (one per 32-wide k-step).  The fragments of the next group are
-    // requested from LDS before the current group's MFMAs are issued; the one barrier per tile sits BETWEEN the two groups:
-    // by then this wave holds every fragment of tile kt (buffer kt&1 is free: the LDS-DMA of tile kt+2 goes straight into it,
-    // two tiles of prefetch with two buffers) and tile kt+1 has landed (its first fragments load under the second group).
-    auto ld = [&](v8 (&fw)[4], v8 (&fx)[8], const char* tW, const char* tX, int ks) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fw[i] = lds_frag<T>(tW, wn * 64 + i * 16 + x, ks, g);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) fx[j] = lds_frag<T>(tX, wm * 128 + j * 16 + x, ks, g);
-    };
-    auto mm = [&](const v8 (&fw)[4], const v8 (&fx)[8], int i0, int i1) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = i0; i < i1; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) mma16(acc[i][j], fw[i], fx[j]);
-    };
-    glds_tile(0, 0);
-    if (nk > 1) glds_tile(1, 1);
-    __syncthreads();
-    v8 fwA[4], fxA[8], fwB[4], fxB[8];
-    ld(fwA, fxA, sW, sX, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        // (the LDS counter is in-order and hipcc waits for ALL outstanding reads at the first MFMA of a group, so the next
-        // group's requests go out after the first half of this group's MFMAs rather than before them)
-        mm(fwA, fxA, 0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        ld(fwB, fxB, sW + buf * BIG_TILE_BYTES, sX + buf * BIG_TILE_BYTES, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(fwA, fxA, 2, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA is ordered by the issuing wave's vmcnt + a barrier: tile kt+1
-        __syncthreads();                                      // has landed for everyone, and this wave's reads of tile kt are done
-        if (kt + 2 < nk) glds_tile(kt + 2, buf);
-        if (kt + 1 < nk) ld(fwA, fxA, sW + (buf ^ 1) * BIG_TILE_BYTES, sX + (buf ^ 1) * BIG_TILE_BYTES, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(fwB, fxB, 0, 4);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int m = m0 + wm * 128 + j * 16 + x;
-        if (m >= M) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + g * 4;
-            if (n >= N) continue;
-            f32x4 v = acc[i][j];
-            if (bias) {
-                const bf16x4 bv = *(const bf16x4*)(bias + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
-            }
-            v *= scale;
-            if (ACT == MMGL_ACT_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            T* yp = Y + (size_t)m * N + n;
-            if (accumulate) {
-                const bf16x4 ov = *(const bf16x4*)yp;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
-            }
-            if (zmask) {                                      // ReLU backward of the producer of this GEMM's output-side operand
-                const bf16x4 mv = *(const bf16x4*)(zmask + (size_t)m * N + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = ((float)mv[r] > 0.f) ? v[r] : 0.f;
-            }
-            *(bf16x4*)yp = __builtin_convertvector(v, bf16x4);
-        }
-    }
-}
-
-// shape test shared by launch_gemm and the backward planners: the 256x256 kernel needs whole 64-wide K tiles and enough
-// tiles to fill the chip twice (below that the 128x128 kernel's finer tiling wins)
+// shape test of the backward planners: a dgrad whose output fills the chip twice with 256x256 tiles runs as an NT GEMM against a
+// transposed copy of the weight (the persistent kernel of gemm8p.hip), smaller ones on the transposition-free 128x128 kernel
 inline bool big_tile_shape(int M, int N, int K) { return K % 64 == 0 && (size_t)cdiv(M, 256) * cdiv(N, 256) >= 512; }
 
 // the persistent ping-pong kernel (gemm8p.hip) takes every bf16 shape it supports; the 256x256 / 128x128 kernels of this file are
@@ -340,7 +211,6 @@ inline int launch_gemm8p_rows(const bf16* X, int ldx, const bf16* W, int ldw, bf
     return launch_gemm_mid(X + (size_t)m1 * ldx, ldx, W, ldw, Y + o, ldy, bias, resid ? resid + o : nullptr, zmask ? zmask + o : nullptr, M - m1, N, K,
                            act, scale, st);
 }
-inline constexpr int tune_gemm_big() { return 1; }
 
 // out[C,R] = transpose(f(in[R,C])) with f = (* scale) and optional ReLU mask from yact[R,C] (> 0);
 // optional colsum[C] (+)= sum over R of f(in) (fp32 atomics are avoided: one block owns a full column strip).
@@ -416,21 +286,6 @@ int launch_gemm(const T* X, const T* W, T* Y, const T* bias, int M, int N, int K
         if (!X2 && !accumulate && tune_gemm_8p() && gemm8p_supported(M, N, K, K, K, N) && cdiv(M, 256) * cdiv(N, 256) >= tune_gemm_8p_min_tiles()) {
             if (zmask_done) *zmask_done = zmask != nullptr;
             return launch_gemm8p_rows((const bf16*)X, K, (const bf16*)W, K, (bf16*)Y, N, (const bf16*)bias, nullptr, (const bf16*)zmask, M, N, K, act, scale, st);
-        }
-        // big-tile kernel when the shape fills the chip with 256x256 tiles (>= 2 tiles per CU keeps the tail small)
-        if (!X2 && tune_gemm_big() && big_tile_shape(M, N, K)) {
-            const int tm = cdiv(M, BT), tn = cdiv(N, BT);
-            const size_t ldsb = 4 * BIG_TILE_BYTES;
-            const void* kb = act == MMGL_ACT_RELU ? (const void*)gemm_nt256_kernel<MMGL_ACT_RELU> : (const void*)gemm_nt256_kernel<MMGL_ACT_NONE>;
-            hipError_t eb = hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-            if (eb != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(eb));
-            if (act == MMGL_ACT_RELU)
-                hipLaunchKernelGGL((gemm_nt256_kernel<MMGL_ACT_RELU>), dim3(tm * tn), dim3(512), ldsb, st, X, W, Y, bias, M, N, K, scale, accumulate, tm, tn, (const bf16*)zmask);
-            else
-                hipLaunchKernelGGL((gemm_nt256_kernel<MMGL_ACT_NONE>), dim3(tm * tn), dim3(512), ldsb, st, X, W, Y, bias, M, N, K, scale, accumulate, tm, tn, (const bf16*)zmask);
-            MMGL_CHECK_LAUNCH("gemm_nt256");
-            if (zmask_done) *zmask_done = zmask != nullptr;
-            return MMGL_OK;
         }
     }
     if constexpr (sizeof(T) == 2) {
@@ -701,131 +556,6 @@ __global__ __launch_bounds__(256) void gemm_tx_kernel(const bf16* __restrict__ A
     }
 }
 
-// Large-shape weight gradient (bf16): Out[RB][RA] = scale * sum_k B(k, rb) A(k, ra), both operands k-major straight from memory
-// (dW = dyp^T x: A = x [M][K_in], B = dyp [M][N], contraction over the M rows).  256x256 block tile, 8 waves as 4 (A) x 2 (B),
-// wave tile 64 x 128, two K-tile buffers of [64 k][256 cols] per operand kept as two 128-column halves so the tr16 fragment
-// reader and the source-side 32-byte-slot swizzle of gemm_tx_kernel apply unchanged.  Needs RA, RB % 256 == 0, K % 64 == 0.
-template <int DUMMY>
-__global__ __launch_bounds__(512, 1) void gemm_tt256_kernel(const bf16* __restrict__ Aop, int lda, const bf16* __restrict__ Bop,
-                                                            int ldb, bf16* __restrict__ Out, float* __restrict__ part, int RA, int RB,
-                                                            int K, float scale, int accumulate, int tiles_a, int tiles_b, int nsplit) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int HALF = 64 * 256;             // bytes of one [64 k][128 cols] half tile
-    char* sA = smem;                           // [2 buffers][2 halves][HALF]
-    char* sB = smem + 4 * HALF;
-    // split-K for small outputs (a 2048x2048 weight is only 64 tiles): split s contracts rows [s*K/nsplit, (s+1)*K/nsplit) and
-    // writes an fp32 partial tile; splitk_reduce_kernel folds them in a fixed order (deterministic, no atomics)
-    const int vid = xcd_remap(blockIdx.x, tiles_a * tiles_b * nsplit);
-    const int split = vid % nsplit, tile = vid / nsplit;
-    int ta, tb;
-    if (MMGL_TILE_GROUPED) grouped_tile(tile, tiles_b, tiles_a, tb, ta);
-    else { ta = tile / tiles_b; tb = tile % tiles_b; }
-    const int kchunk = K / nsplit;
-    Aop += (size_t)split * kchunk * lda;
-    Bop += (size_t)split * kchunk * ldb;
-    K = kchunk;
-    const int a0 = ta * 256, b0 = tb * 256;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x = lane & 15, g = lane >> 4;
-    const int wa = wave >> 1, wb = wave & 1;
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = vzero<f32x4>();
-
-    auto glds_kmajor = [&](const bf16* op, int ld, int col0, int k0, char* dst) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int rbase = (i * 8 + wave) * 4;                          // 4 k-rows (1 KiB) per wave instruction
-                const int row = rbase + (lane >> 4);
-                const int s16 = lane & 15;
-                const int c16 = ((((s16 >> 1) ^ (row & 7)) << 1) | (s16 & 1));
-                const bf16* gp = op + (size_t)(k0 + row) * ld + col0 + h * 128 + c16 * 8;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                 (__attribute__((address_space(3))) void*)(dst + h * HALF + rbase * 256), 16, 0, 0);
-            }
-    };
-    const int nk = K / 64;
-    // same software pipeline as gemm_nt256_kernel: fragments one group ahead, one barrier per tile between the two groups,
-    // the LDS-DMA of tile kt+2 issued right after it into the buffer this wave has just finished reading
-    auto ld = [&](bf16x8 (&fa)[4], bf16x8 (&fb)[8], const char* tA, const char* tB, int ks) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int blk = wa * 4 + i;
-            fa[i] = tfrag_kmajor_swz(tA + (blk >> 3) * HALF, blk & 7, ks, lane);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int blk = wb * 8 + j;
-            fb[j] = tfrag_kmajor_swz(tB + (blk >> 3) * HALF, blk & 7, ks, lane);
-        }
-    };
-    auto mm = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[8], int i0, int i1) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = i0; i < i1; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) mma16(acc[i][j], fa[i], fb[j]);
-    };
-    glds_kmajor(Aop, lda, a0, 0, sA);
-    glds_kmajor(Bop, ldb, b0, 0, sB);
-    if (nk > 1) {
-        glds_kmajor(Aop, lda, a0, 64, sA + 2 * HALF);
-        glds_kmajor(Bop, ldb, b0, 64, sB + 2 * HALF);
-    }
-    __syncthreads();
-    bf16x8 faA[4], fbA[8], faB[4], fbB[8];
-    ld(faA, fbA, sA, sB, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        mm(faA, fbA, 0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        ld(faB, fbB, sA + buf * 2 * HALF, sB + buf * 2 * HALF, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(faA, fbA, 2, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 2 < nk) {
-            glds_kmajor(Aop, lda, a0, (kt + 2) * 64, sA + buf * 2 * HALF);
-            glds_kmajor(Bop, ldb, b0, (kt + 2) * 64, sB + buf * 2 * HALF);
-        }
-        if (kt + 1 < nk) ld(faA, fbA, sA + (buf ^ 1) * 2 * HALF, sB + (buf ^ 1) * 2 * HALF, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(faB, fbB, 0, 4);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (nsplit > 1) {
-        float* pp = part + (size_t)split * RA * RB;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *(f32x4*)(pp + (size_t)(b0 + wb * 128 + j * 16 + x) * RA + a0 + wa * 64 + i * 16 + g * 4) = acc[i][j];
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int rbi = b0 + wb * 128 + j * 16 + x;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rai = a0 + wa * 64 + i * 16 + g * 4;
-            f32x4 v = acc[i][j] * scale;
-            bf16* op = Out + (size_t)rbi * RA + rai;
-            if (accumulate) {
-                const bf16x4 ov = *(const bf16x4*)op;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)ov[r];
-            }
-            *(bf16x4*)op = __builtin_convertvector(v, bf16x4);
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, bf16* __restrict__ out, size_t n4,
                                                             int nsplit, float scale, int accumulate) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -841,26 +571,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-// number of K splits of the big weight-gradient kernel (0 = shape not eligible)
-inline int tt256_splits(int RA, int RB, int K) {
-    if (RA % 256 || RB % 256 || K % 64) return 0;
-    const int tiles = (RA / 256) * (RB / 256);
-    if (tiles >= 192) return 1;
-    for (int s = 2; s <= 8; s *= 2)
-        if (tiles * s >= 192 && K % (64 * s) == 0 && K / s >= 1024) return s;
-    return 0;
-}
-inline size_t tt256_partial_bytes_wgrad(int RA, int RB, int K);
+inline size_t wgrad_partial_bytes(int RA, int RB, int K);
 // the split-partial region of a linear's backward workspace: the weight gradient's K-split tiles (RA = in, RB = out features,
 // contraction over the M rows) or, before them on the same stream, the dgrad's ([M, in] outputs, contraction over out features)
-inline size_t tt256_partial_bytes(int RA, int RB, int K) {
-    const size_t a = tt256_partial_bytes_wgrad(RA, RB, K), b = align_up(gemm8p_split_bytes(K, RA, RB), 256);
+inline size_t split_partial_bytes(int RA, int RB, int K) {
+    const size_t a = wgrad_partial_bytes(RA, RB, K), b = align_up(gemm8p_split_bytes(K, RA, RB), 256);
     return a > b ? a : b;
 }
-inline size_t tt256_partial_bytes_wgrad(int RA, int RB, int K) {
-    int s = tt256_splits(RA, RB, K);
-    const int s8 = gemm8p_tt_splits(RA, RB, K);
-    if (s8 > s) s = s8;
+inline size_t wgrad_partial_bytes(int RA, int RB, int K) {
+    const int s = gemm8p_tt_splits(RA, RB, K);
     return s > 1 ? align_up((size_t)s * RA * RB * sizeof(float), 256) : 0;
 }
 
@@ -964,25 +683,6 @@ int launch_gemm_tx(bool tb, const bf16* Aop, int lda, const bf16* Bop, int ldb, 
             return MMGL_OK;
         }
     }
-    const int nsplit = (tb && !ymask && tune_gemm_big()) ? tt256_splits(RA, RB, K) : 0;
-    if (nsplit == 1 || (nsplit > 1 && part)) {
-        // both operands k-major and a full chip of 256x256 tiles (with K splits for small outputs): the big-tile kernel
-        const int ta = RA / 256, tbn = RB / 256;
-        const size_t ldsb = 8 * 64 * 256;
-        auto kf = gemm_tt256_kernel<0>;
-        hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-        if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(kf, dim3(ta * tbn * nsplit), dim3(512), ldsb, st, Aop, lda, Bop, ldb, Out, part, RA, RB, K, scale, accumulate,
-                           ta, tbn, nsplit);
-        MMGL_CHECK_LAUNCH("gemm_tt256");
-        if (nsplit > 1) {
-            const size_t n4 = (size_t)RA * RB / 4;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256)), dim3(256), 0, st, part,
-                               Out, n4, nsplit, scale, accumulate);
-            MMGL_CHECK_LAUNCH("splitk_reduce");
-        }
-        return MMGL_OK;
-    }
     const int tiles_a = cdiv(RA, 128), tiles_b = cdiv(RB, 128);
     const size_t lds = 4 * TX_TILE_BYTES;
     // LDS-DMA staging needs whole tiles along every k-major dimension and no ReLU mask (the mask is applied once, upstream)
@@ -1032,7 +732,7 @@ int linear_dgrad(const T* dy, const T* y, const T* W, T* dx, char* ws, int M, in
             a = (const bf16*)ws;
             sc = 1.f;
         }
-        if (tune_gemm_big() && big_tile_shape(M, K, N)) {
+        if (big_tile_shape(M, K, N)) {
             T* Wt = (T*)(ws + bf16_wt_offset(M, N, act));
             int rc = launch_transpose<T>(W, nullptr, Wt, nullptr, N, K, 1.f, 0, st);
             if (rc) return rc;
@@ -1091,12 +791,12 @@ int linear_wgrad(const T* dy, const T* y, const T* x, T* dW, T* dbias, char* ws,
 
 size_t dgrad_ws(int M, int N, int K, int act, size_t esz) {
     const size_t Np = (size_t)(N + 7) / 8 * 8;
-    if (esz == 2) return bf16_part_offset(M, N, K, act) + tt256_partial_bytes(K, N, M);
+    if (esz == 2) return bf16_part_offset(M, N, K, act) + split_partial_bytes(K, N, M);
     return align_up((size_t)K * Np * esz, 256) + (act ? align_up((size_t)M * N * esz, 256) : 0);
 }
 size_t wgrad_ws(int M, int N, int K, size_t esz) {
     const size_t Mp = (size_t)(M + 7) / 8 * 8;
-    if (esz == 2) return bf16_part_offset(M, N, K, 1) + tt256_partial_bytes(K, N, M);
+    if (esz == 2) return bf16_part_offset(M, N, K, 1) + split_partial_bytes(K, N, M);
     return align_up((size_t)N * Mp * esz, 256) + align_up((size_t)K * Mp * esz, 256);
 }
 
@@ -1212,7 +912,7 @@ int linear_bwd(const T* dy, const T* y, const T* x, const T* W, T* dx, T* dW, T*
         }
         int rc = MMGL_OK;
         if (dx) {
-            if (tune_gemm_big() && (big_tile_shape(M, K, N) || (N % 128 == 0 && mmgl_gemm_nt_fast(M, K, N, N, N, K, MMGL_BF16)))) {
+            if ((big_tile_shape(M, K, N) || (N % 128 == 0 && mmgl_gemm_nt_fast(M, K, N, N, N, K, MMGL_BF16)))) {
                 // (sending every M >= 1024 dgrad through W^T and the 128x128 NT kernel was tried: no gain in the batch-4 step)
                 // shapes the persistent kernel takes (a chip of 256x256 tiles, or K-split work items at the reference's small
                 // batch): dx = dyp . (W^T)^T as an NT GEMM; transposing the [N,K] weight costs a few percent of the GEMM

@@ -724,202 +724,6 @@ __global__ __launch_bounds__(128 * PAR) void selfattn_bwd_dkv_kernel(const T* __
     }
 }
 
-// ============================================================================================ backward: dK, dV (bf16, D <= 64)
-// One WAVE = one workgroup = (b, h, 64-key group): twice the keys per wave of the generic kernel above, no parity split.
-// The generic kernel moves 16 KiB through LDS (tile write + tr16 reads) per 32 MFMAs per wave -- with 4 waves per CU that
-// is the whole 128 B/clk LDS port; here the same 16 KiB feed 64 MFMAs.  K / V fragments are loaded once, straight from
-// global memory into registers (they are the B operands of S = Q K^T and dP = dO V^T); Q / dO row fragments, LSE and
-// delta are requested one tile ahead (vmcnt is a single in-order counter: a load consumed in the iteration that issues it
-// would also wait for the prefetches queued before it) into a second register set -- the loop is unrolled by two and the
-// sets swap roles, so nothing is copied -- and dropped into the wave-private tile for the transposed (tr16) reads of
-// dV += P^T dO, dK += dS^T Q.  Branch-free body: bounds by buffer descriptors, masks by selects feeding exp2(-inf) = 0.
-// No barrier, no cross-wave reduction: every dK / dV element is produced by one wave.
-// NSBW = 16-key blocks per wave: 4 (64 keys) up to D = 64, 2 (32 keys) at D = 128 (the dK / dV accumulators are NSBW * D / 4 registers each)
-// Two register sets for the Q / dO rows: the next tile is in flight during this one (what a lone wave per SIMD needs).  (A
-// 32-keys-per-wave, one-register-set form that fits two waves per SIMD was 15-38 % slower: every wave re-reads the whole Q / dO tile.)
-template <int D, int NSBW>
-__global__ __launch_bounds__(64) void selfattn_bwd_dkv64_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ q,
-                                                                const bf16* __restrict__ k, const bf16* __restrict__ v,
-                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                const uint8_t* __restrict__ valid, bf16* __restrict__ dk,
-                                                                bf16* __restrict__ dv, int B, int H, int T_, int nkb, int ldq, int ldg,
-                                                                int P, int ldk) {
-    typedef bf16 T;
-    const int Tk = T_ + P;                         // keys: P always-visible prefix rows, then the T causal ones
-    typedef XC<T, D, NSBW> C;
-    constexpr int KW = 16 * NSBW;                  // keys per wave
-    typedef bf16x8 v8;
-    constexpr int LDT = C::DPAD + 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Qt = (T*)smem;                              // [32][LDT]
-    T* Gt = Qt + 32 * LDT;
-    const int lane = threadIdx.x;
-    const int x = lane & 15, g = lane >> 4;
-
-    const int vid = xcd_remap(blockIdx.x, B * H * nkb);
-    const int bh = vid / nkb, kblk = vid % nkb;                 // low key groups (most query tiles) first
-    const int b = bh / H, h = bh % H;
-    const size_t HD = (size_t)H * D;
-    const int s0 = kblk * KW;
-    const uint32_t rbq = (uint32_t)(ldq * sizeof(T)), rbo = (uint32_t)(HD * sizeof(T)), rbk = (uint32_t)(ldk * sizeof(T));
-    const uint32_t slabq = (uint32_t)(((size_t)(T_ - 1) * ldq + D) * sizeof(T)), slabo = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
-    const uint32_t slabk = (uint32_t)(((size_t)(Tk - 1) * ldk + D) * sizeof(T));
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * ldq + h * D, slabq);
-    const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * Tk * ldk + h * D, slabk);
-    const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * Tk * ldk + h * D, slabk);
-    const __amdgpu_buffer_rsrc_t rg = make_rsrc(dout + (size_t)b * T_ * HD + h * D, slabo);
-    const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
-    const __amdgpu_buffer_rsrc_t rd = make_rsrc(delta + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
-
-    v8 kf[NSBW][C::NDC], vf[NSBW][C::NDC];
-    float kbias[NSBW];                                // 0 for a real, valid key of this lane's column; -inf otherwise
-    // One wave per SIMD and nothing else to run: every exposed memory round trip of the prologue is idle time.  The key-valid bytes
-    // are only LOADED here and turned into kbias after the first query tiles have been requested too (a compare right behind each
-    // load made hipcc wait -- vmcnt(0) -- four times in a row, each time also for the K / V loads issued in between).
-    uint8_t kvalid[NSBW];
-#pragma unroll
-    for (int sbl = 0; sbl < NSBW; ++sbl) {
-        const int s = s0 + sbl * 16 + x;
-        kvalid[sbl] = valid[(size_t)b * Tk + min(s, Tk - 1)];
-#pragma unroll
-        for (int dc = 0; dc < C::NDC; ++dc) {
-            kf[sbl][dc] = buf_load8<T>(rk, row_off<T, C>(s, rbk, dc * 32 + g * 8));
-            vf[sbl][dc] = buf_load8<T>(rv, row_off<T, C>(s, rbk, dc * 32 + g * 8));
-        }
-    }
-    f32x4 dva[C::NDB][NSBW], dka[C::NDB][NSBW];
-#pragma unroll
-    for (int db = 0; db < C::NDB; ++db)
-#pragma unroll
-        for (int sbl = 0; sbl < NSBW; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
-
-    auto request = [&](int tbase, v8 (&qn)[2][C::NDC], v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-#pragma unroll
-            for (int dc = 0; dc < C::NDC; ++dc) {
-                qn[tb][dc] = buf_load8<T>(rq, row_off<T, C>(tbase + tb * 16 + x, rbq, dc * 32 + g * 8));
-                gn[tb][dc] = buf_load8<T>(rg, row_off<T, C>(tbase + tb * 16 + x, rbo, dc * 32 + g * 8));
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t o = (uint32_t)(tbase + tb * 16 + g * 4 + r) * 4u;
-                ln[tb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
-                dn[tb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, o, 0, 0));
-            }
-        }
-    };
-
-    // One 32-row step.  The tile's Q^T / dO^T fragments are fetched FIRST (tile write, transposed reads), so that the key-block
-    // loop below is free of fences: block sbl's exp / dS arithmetic (VALU) has the S / dP MFMAs of block sbl+1 and the
-    // dV / dK MFMAs of block sbl-1 to overlap with -- one wave per SIMD, so the overlap has to come from inside the wave.
-    // VALU diet: -lse and -delta enter as the MFMA C-inputs (acc = s - lse, dp - delta directly), the key-valid bias is one
-    // packed add, the causal select exists only in the two diagonal steps (DIAG).
-    auto step = [&](auto diag_tag, int t0, v8 (&qa)[2][C::NDC], v8 (&ga)[2][C::NDC], float (&la)[2][4], float (&da)[2][4],
-                    v8 (&qn)[2][C::NDC], v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
-        constexpr bool DIAG = decltype(diag_tag)::value;
-        request(t0 + 32, qn, gn, ln, dn);
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int dc = 0; dc < C::NDC; ++dc) {
-                *(v8*)(Qt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = qa[tb][dc];
-                *(v8*)(Gt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = ga[tb][dc];
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        v8 gT[C::NDB], qT[C::NDB];
-#pragma unroll
-        for (int db = 0; db < C::NDB; ++db) {
-            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-            const bf16* pg = Gt + (4 * g + (x >> 2)) * LDT + db * 16 + (x & 3) * 4;
-            const bf16* pq = Qt + (4 * g + (x >> 2)) * LDT + db * 16 + (x & 3) * 4;
-            const bf16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pg);
-            const bf16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pg + 16 * LDT));
-            const bf16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pq);
-            const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pq + 16 * LDT));
-            gT[db] = v8{g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-            qT[db] = v8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next step's tile write stays behind these reads
-        __builtin_amdgcn_wave_barrier();
-        f32x4 nl[2], nd[2];                                          // C-inputs: -lse (-inf for a row past T: p = 0), -delta
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                nl[tb][r] = (t0 + tb * 16 + g * 4 + r < T_) ? -la[tb][r] : -INFINITY;
-                nd[tb][r] = -da[tb][r];
-            }
-#pragma unroll
-        for (int sbl = 0; sbl < NSBW; ++sbl) {
-            f32x4 pr[2], dsr[2];
-            const int s = s0 + sbl * 16 + x;
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
-                f32x4 sa = nl[tb] + kbias[sbl], pa = nd[tb];
-#pragma unroll
-                for (int dc = 0; dc < C::NDC; ++dc) {
-                    mma16(sa, qa[tb][dc], kf[sbl][dc]);
-                    mma16(pa, ga[tb][dc], vf[sbl][dc]);
-                }
-                f32x4 e = sa * LOG2E;
-                if constexpr (DIAG) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) e[r] = (s <= t0 + tb * 16 + g * 4 + r + P) ? e[r] : -INFINITY;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pr[tb][r] = __builtin_amdgcn_exp2f(e[r]);
-                dsr[tb] = pr[tb] * pa;
-            }
-            const v8 pB = pack8<T>(pr[0], pr[1]), dsB = pack8<T>(dsr[0], dsr[1]);
-#pragma unroll
-            for (int db = 0; db < C::NDB; ++db) {
-                mma16(dva[db][sbl], gT[db], pB);
-                mma16(dka[db][sbl], qT[db], dsB);
-            }
-        }
-    };
-
-    typedef std::integral_constant<bool, true> on_diag;
-    typedef std::integral_constant<bool, false> off_diag;
-    // query rows that can see this key group start at s0 - P (key s is visible to row t iff s <= t + P); a step is diagonal
-    // (needs the causal select) while some of its rows precede some key of the group
-    const int tstart = max(s0 - P, 0) & ~31;
-    const int tdiag = s0 + KW - 1 - P;                               // steps with t0 < tdiag are diagonal
-    auto finish_kbias = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int sbl = 0; sbl < NSBW; ++sbl) kbias[sbl] = (s0 + sbl * 16 + x < Tk && kvalid[sbl] != 0) ? 0.f : -INFINITY;
-    };
-    {
-        v8 qA[2][C::NDC], gA[2][C::NDC], qB[2][C::NDC], gB[2][C::NDC];
-        float lA[2][4], dA[2][4], lB[2][4], dB[2][4];
-        request(tstart, qA, gA, lA, dA);
-        finish_kbias();
-        int t0 = tstart;
-        for (; t0 < T_ && t0 < tdiag; t0 += 64) {                    // diagonal steps (two without a prefix, up to three with one)
-            step(on_diag(), t0, qA, gA, lA, dA, qB, gB, lB, dB);
-            if (t0 + 32 < T_) step(on_diag(), t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
-        }
-        for (; t0 < T_; t0 += 64) {
-            step(off_diag(), t0, qA, gA, lA, dA, qB, gB, lB, dB);
-            if (t0 + 32 < T_) step(off_diag(), t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
-        }
-    }
-#pragma unroll
-    for (int sbl = 0; sbl < NSBW; ++sbl) {
-        const int s = s0 + sbl * 16 + x;
-        if (s < Tk) {
-            const size_t off = ((size_t)b * Tk + s) * ldg + h * D + g * 4;
-#pragma unroll
-            for (int db = 0; db < C::NDB; ++db) {
-                store4<T>(dk + off + db * 16, dka[db][sbl]);
-                store4<T>(dv + off + db * 16, dva[db][sbl]);
-            }
-        }
-    }
-}
-
 // ============================================================================================ host
 template <typename K> int set_lds_sa(K kern, size_t bytes) {
     if (bytes > 160 * 1024) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "selfattn: needs %zu B of LDS (> 160 KiB)", bytes);
@@ -977,20 +781,6 @@ int sa_bwd(const void* dout, const void* q, const void* k, const void* v, const 
             if (par == 2 && red > tiles) tiles = red;
             return sizeof(T) * 4 * C::ROWIMG + tiles;
         };
-        constexpr int use64 = 1;
-        if constexpr (sizeof(T) == 2) {
-            if (use64) {
-                constexpr int NSBW = D <= 64 ? 4 : 2;
-                typedef XC<bf16, D, NSBW> C4;
-                const int nkb64 = cdiv(T_ + P, 16 * NSBW);
-                const size_t lds64 = sizeof(bf16) * 2 * 32 * (C4::DPAD + 16);
-                hipLaunchKernelGGL((selfattn_bwd_dkv64_kernel<D, NSBW>), dim3(B * H * nkb64), dim3(64), lds64, st, (const bf16*)dout,
-                                   (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, (bf16*)dk, (bf16*)dv, B, H, T_,
-                                   nkb64, ldq, ldgk, P, ldk);
-                MMGL_CHECK_LAUNCH("selfattn_bwd_dkv64");
-                return MMGL_OK;
-            }
-        }
         if (lds_for(2) <= 160 * 1024) {
             auto kern = selfattn_bwd_dkv_kernel<T, D, 2>;
             int rc = set_lds_sa(kern, lds_for(2));

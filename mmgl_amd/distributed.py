@@ -75,10 +75,10 @@ class DataParallelEngine:
         if any(p.dtype != self.dtype or p.device != self.device for p in self.params):
             raise ValueError("DataParallelEngine: trainable parameters must share one dtype and device")
         self.fused = self.device.type == "cuda" if fused is None else fused
-        if self.exchange and self.device.type == "cuda":
-            if os.environ.get("MMGL_GEMM_DYNAMIC", "1") != "0":
-                from . import ops
-                ops.gemm_dynamic_schedule(True, self.device)      # the GEMMs of the backward pass share the CUs with the all-reduces
+        dyn = os.environ.get("MMGL_GEMM_DYNAMIC", "1")       # "0": static always; "1": dynamic when collectives share the GPU; "2": always
+        if self.device.type == "cuda" and ((self.exchange and dyn != "0") or dyn == "2"):
+            from . import ops
+            ops.gemm_dynamic_schedule(True, self.device)          # the GEMMs of the backward pass share the CUs with the all-reduces
         if master_weights is None:
             master_weights = self.dtype != torch.float32
 

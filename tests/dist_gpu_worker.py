@@ -60,6 +60,7 @@ def main():
         model(**batch_of(rank, step)).loss.backward()
         engine.finish_backward()
         assert engine.last_launch_order == list(range(len(engine.buckets))), engine.last_launch_order
+        report["launch_order"] = list(engine.last_launch_order)
         got = engine.flat_grad.clone()
         # (b) the same sum without any exchange: every rank's batch, accumulated locally
         engine.zero_grad()
@@ -85,7 +86,6 @@ def main():
     assert all(torch.equal(both[0], t) for t in both[1:]), "parameters diverged across ranks"
     report["params_equal"] = True
     report["exchange_bytes"] = engine.exchange_bytes
-    report["launch_order"] = engine.last_launch_order
     if rank == 0:
         print(json.dumps(report), flush=True)
     dist.barrier()

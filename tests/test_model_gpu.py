@@ -227,6 +227,9 @@ def test_prefix_tuning_equals_hf_opt_with_past_key_values(pre_ln):
     assert_close(t_dev.grad, t_ref.grad, 5e-3, "d loss / d prefix table")
 
 
+BF16_LOGITS_TOL = 4e-2          # max |bf16 HIP logit - fp32 oracle logit| / max |oracle logit| at full size (measured: see the test's print)
+
+
 @pytest.mark.parametrize("name,nsamp", [("opt-1.3b", 1), ("opt-125m", 2)])
 def test_full_size_step_matches_cpu_oracle(name, nsamp):
     """BASELINE.json config 3 (OPT-1.3B, d = 2048, 24 + 4 layers, 11 + 5 neighbors) and config 2 (OPT-125m, d = 768, 12 + 4 layers,
@@ -292,6 +295,16 @@ def test_full_size_step_matches_cpu_oracle(name, nsamp):
     print(f"full-size {name}, {nsamp} sample(s): HIP bf16 loss {float(out.loss):.5f} vs CPU oracle fp32 {float(ref_loss):.5f}")
     assert torch.isfinite(out.loss)
     assert abs(float(out.loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
+    # bf16 logits at full size against the fp32 oracle, on the summary positions evaluate_loop reads (run_generation.py:584-591):
+    # activations, weights and the logits themselves are bf16 (8 mantissa bits: 2^-9 = 2e-3 per rounding) through 24 + 4 layers.
+    # Measured (round 4): see BF16_LOGITS_TOL; the argmax -- what CIDEr is computed from -- agrees on >= 90 % of the positions of a
+    # RANDOM-INIT model, whose top-2 logits are often closer than that error (tests/test_acceptance_gpu.py does the trained case)
+    lg_bf = out.logits[:, L_in:-1].float().cpu()
+    e_bf = float((lg_bf - ref_logits[:, L_in:-1]).abs().max() / ref_logits[:, L_in:-1].abs().max())
+    e_bf_rms = float((lg_bf - ref_logits[:, L_in:-1]).pow(2).mean().sqrt() / ref_logits[:, L_in:-1].pow(2).mean().sqrt())
+    agree_bf = (lg_bf.argmax(-1) == ref_logits[:, L_in:-1].argmax(-1)).float().mean().item()
+    print(f"   bf16 logits vs fp32 CPU oracle (summary positions): max-norm rel err {e_bf:.3e}, rms rel err {e_bf_rms:.3e}, argmax agreement {agree_bf:.4f}")
+    assert e_bf <= BF16_LOGITS_TOL and e_bf_rms <= BF16_LOGITS_TOL / 2, (e_bf, e_bf_rms)
     params = dict(dev.named_parameters())
     # Scalar gates: d loss / d gate = sum over the sample's 640 x 2048 activations of (upstream gradient x block output) -- 1.3 M signed
     # bf16 products that cancel down to 1e-4 .. 1e-2.  The bf16 rounding noise of such a sum is an ABSOLUTE floor (measured: 1e-5 ..

@@ -239,3 +239,89 @@ def test_cli_entry_point_synthetic(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "examples/sec" in r.stdout and "cider" in r.stdout
     assert os.path.exists(os.path.join(str(tmp_path), "default_0", "ckpt.pth.tar"))
+
+
+def test_six_optimizer_steps_follow_the_oracle_trajectory():
+    """Trainer trajectory parity (reference language_modelling/run_generation.py:321-333, 466-494): `train_loop` on the fp32 HIP path
+    (dropout 0) -- 12 micro-batches, grad accumulation 2, linear warm-up over 2 optimizer steps, StepLR(step 2, gamma 0.5), fused AdamW
+    over the flat buffers -- against the CPU oracle's autograd + torch.optim.AdamW + torch's own StepLR on the same batches: the lr
+    sequence is equal, and after 6 optimizer steps every trainable parameter agrees to 1e-4 of its largest element (Adam divides by
+    sqrt(v): the test is as tight as a first-order method allows; k_proj.bias, whose gradient is analytically zero -- softmax ignores a
+    per-row score shift -- receives pure round-off and Adam turns round-off into +-lr steps, so it is compared to the INITIAL value
+    plus at most 6 lr instead)."""
+    import copy
+    from types import SimpleNamespace
+    from mmgl_amd.distributed import DataParallelEngine
+    from mmgl_amd.language_modelling.run_generation import WarmupStepLR, train_loop
+    from mmgl_amd.model import CrossAttentionModel
+    from oracle import lm_ref, wrapper_ref
+
+    fx = Fixture("g1_wrapper_all.npz")
+    base_lr, accum, n_opt, warmup, step_size, gamma = 2e-3, 2, 6, 2, 2, 0.5
+    w = CrossAttentionModel(mpt_args(context="all"), tokenizer=None, lm_config=tiny_opt_config(dropout=0.0), text_config=tiny_roberta_config(),
+                            visual_config=tiny_clip_vision_config())
+    load_exact(w, fx.p)
+    w = w.cuda().train()
+    trainable = [n for n, p in w.named_parameters() if p.requires_grad]
+    T = fx.inp["input_ids"].shape[1]
+    lin = T - 8                                                       # mpt_args: max_output_length 8
+
+    def micro_batch(i):
+        g = torch.Generator().manual_seed(700 + i)
+        b = {k: v.clone() for k, v in fx.inp.items()}
+        b["input_ids"] = torch.where(b["attention_mask"].bool(), torch.randint(3, 128, b["input_ids"].shape, generator=g), b["input_ids"])
+        b["labels"] = b["input_ids"].clone()
+        return b
+
+    batches = [micro_batch(i) for i in range(accum * n_opt)]
+    args = SimpleNamespace(steps_per_epoch=len(batches), grad_accumulation_steps=accum, decoder_only=True, max_input_length=lin, print_freq=1,
+                           per_device_train_batch_size=batches[0]["input_ids"].shape[0])
+    engine = DataParallelEngine(w, lr=base_lr, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01)
+    sched = WarmupStepLR(base_lr, warmup, step_size, gamma)
+    hist = train_loop(batches, w, None, engine, 0, sched, args)
+    lrs_hip = [h["lr"] for h in hist]
+    assert len(lrs_hip) == n_opt
+
+    # ---- the oracle's trajectory: functional fp32 forward on CPU, autograd, torch.optim.AdamW, torch's StepLR after a linear warm-up
+    p = {k: v.clone() for k, v in fx.p.items()}
+    for k in trainable:
+        p[k].requires_grad_()
+    cfg = lm_ref.LMConfig(vocab_size=128, hidden_size=64, num_attention_heads=4, ffn_dim=128, num_hidden_layers=4, word_embed_proj_dim=64,
+                          neighbor_layer_wise=2)
+    opt = torch.optim.AdamW([p[k] for k in trainable], lr=base_lr, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01)
+    after = torch.optim.lr_scheduler.StepLR(opt, step_size=step_size, gamma=gamma)
+    lrs_ref, n_sched = [], 0
+    for s in range(n_opt):
+        opt.zero_grad()
+        for a in range(accum):
+            b = batches[s * accum + a]
+            _, loss = wrapper_ref.cross_attention_model_forward(p, cfg, b, fx.out["text_last_hidden"], fx.out["visual_pooled"], "all", 2)
+            (loss / accum).backward()
+        # the reference's order: optimizer.step() at the current lr, then scheduler.step() -- GradualWarmupScheduler(multiplier 1) hands
+        # lr = base * n / warmup for its first `warmup` calls, then defers to StepLR
+        lr = base_lr * n_sched / warmup if n_sched <= warmup else after.get_last_lr()[0]
+        for g in opt.param_groups:
+            g["lr"] = lr
+        lrs_ref.append(lr)
+        opt.step()
+        n_sched += 1
+        if n_sched > warmup:
+            after.step()
+    assert lrs_hip == pytest.approx(lrs_ref, rel=1e-12, abs=0), (lrs_hip, lrs_ref)
+    assert lrs_ref == pytest.approx([0.0, 1e-3, 2e-3, 2e-3, 1e-3, 1e-3], rel=1e-12)
+
+    got = dict(w.named_parameters())
+    worst = ("", 0.0)
+    for k in trainable:
+        ref, g0 = p[k].detach(), got[k].detach().cpu().float()
+        if k.endswith("k_proj.bias"):
+            assert (g0 - fx.p[k]).abs().max() <= sum(lrs_ref) * 1.01 + 1e-6, k
+            continue
+        err = float((g0 - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+        moved = float((ref - fx.p[k]).abs().max() / ref.abs().max().clamp_min(1e-12))
+        if err > worst[1]:
+            worst = (k, err, moved)
+        assert err < 1e-4, (k, err, moved)
+    print(f"trajectory: worst parameter {worst}")
+    moved_any = max(float((p[k].detach() - fx.p[k]).abs().max()) for k in trainable)
+    assert moved_any > 3e-3                                           # the six steps really moved the parameters (~ sum of lrs)

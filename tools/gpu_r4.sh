@@ -1,0 +1,25 @@
+#!/bin/bash
+# round-4 GPU session script: bash tools/gpu_r4.sh <tag> <what...>
+tag=$1; shift
+out=gpurun_out/$tag; mkdir -p $out
+for what in "$@"; do
+case $what in
+  tests_new)
+    python -m pytest tests/test_rccl_gpu.py tests/test_gemm_nt_gpu.py tests/test_encoders_gpu.py tests/test_trainer_gpu.py -q -s 2>&1 | tail -60 > $out/tests_new.log;;
+  tests_full)
+    python -m pytest tests/test_model_gpu.py -q -s -k "full_size_step" 2>&1 | tail -40 > $out/tests_full.log;;
+  tests_all)
+    python -m pytest tests -m gpu -q 2>&1 | tail -40 > $out/tests_all.log;;
+  bench_force)
+    python -X faulthandler bench.py --force-exchange --no-cpu-baseline > $out/bench_force.json 2> $out/bench_force.err; echo "rc=$?" >> $out/bench_force.err;;
+  bench_ab_dyn)
+    python bench.py --no-cpu-baseline > $out/bench_static.json 2> $out/bench_static.err
+    MMGL_GEMM_DYNAMIC=2 python bench.py --no-cpu-baseline > $out/bench_dyn.json 2> $out/bench_dyn.err
+    python bench.py --no-cpu-baseline --config opt-125m > $out/bench125_static.json 2>> $out/bench_static.err
+    MMGL_GEMM_DYNAMIC=2 python bench.py --no-cpu-baseline --config opt-125m > $out/bench125_dyn.json 2>> $out/bench_dyn.err;;
+  bench)
+    python bench.py > $out/bench.json 2> $out/bench.err;;
+  *) echo "unknown $what";;
+esac
+done
+tail -3 $out/*.log 2>/dev/null
