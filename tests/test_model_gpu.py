@@ -227,7 +227,8 @@ def test_prefix_tuning_equals_hf_opt_with_past_key_values(pre_ln):
     assert_close(t_dev.grad, t_ref.grad, 5e-3, "d loss / d prefix table")
 
 
-BF16_LOGITS_TOL = 4e-2          # max |bf16 HIP logit - fp32 oracle logit| / max |oracle logit| at full size (measured: see the test's print)
+BF16_LOGITS_TOL = 2.5e-2        # max |bf16 HIP logit - fp32 oracle logit| / max |oracle logit| at full size; measured (round 4): 1.46e-2 at
+                                # OPT-1.3B (rms 1.38e-2, argmax agreement 0.992), 1.15e-2 at OPT-125m (rms 1.09e-2)
 
 
 @pytest.mark.parametrize("name,nsamp", [("opt-1.3b", 1), ("opt-125m", 2)])
@@ -304,7 +305,7 @@ def test_full_size_step_matches_cpu_oracle(name, nsamp):
     e_bf_rms = float((lg_bf - ref_logits[:, L_in:-1]).pow(2).mean().sqrt() / ref_logits[:, L_in:-1].pow(2).mean().sqrt())
     agree_bf = (lg_bf.argmax(-1) == ref_logits[:, L_in:-1].argmax(-1)).float().mean().item()
     print(f"   bf16 logits vs fp32 CPU oracle (summary positions): max-norm rel err {e_bf:.3e}, rms rel err {e_bf_rms:.3e}, argmax agreement {agree_bf:.4f}")
-    assert e_bf <= BF16_LOGITS_TOL and e_bf_rms <= BF16_LOGITS_TOL / 2, (e_bf, e_bf_rms)
+    assert e_bf <= BF16_LOGITS_TOL and e_bf_rms <= 2e-2, (e_bf, e_bf_rms)
     params = dict(dev.named_parameters())
     # Scalar gates: d loss / d gate = sum over the sample's 640 x 2048 activations of (upstream gradient x block output) -- 1.3 M signed
     # bf16 products that cancel down to 1e-4 .. 1e-2.  The bf16 rounding noise of such a sum is an ABSOLUTE floor (measured: 1e-5 ..
