@@ -972,6 +972,309 @@ __global__ __launch_bounds__(64) void xattn_bwd_fused_kernel(const bf16* __restr
     }
 }
 
+// ============================================================================================ backward, fused, keys split over waves (bf16)
+// The one-pass backward above for the shapes whose dK / dV accumulators do not fit one wave: head_dim 128 and / or 64 < S <= 128
+// (config 5: D = 128, S = 128 -- 512 accumulator registers per wave in the one-wave form).  A workgroup = NW = NSB / 2 waves owns
+// (batch, head, T-chunk); wave w owns KEYS 32 w .. 32 w + 31 for S^T, dP^T, P, dS, dK, dV (128 accumulator registers at D = 128)
+// and CHANNELS of dQ: the contraction dQ^T = K^T dS^T runs over all keys, so the waves trade dS^T (bf16, already in B-operand
+// layout: 2 KiB per wave and tile through LDS) and each finishes NDB / NW channel blocks -- no fp32 partials, no atomics.
+// Per 32-row tile:  the waves load disjoint (row half, channel chunk) pieces of Q / dO (HBM and L2 see every byte once) into a
+// shared, parity-double-buffered LDS tile [B1]; swapped products for the wave's keys (lane = query row), P from the saved LSE,
+// partial delta = sum over the wave's keys of P dP to LDS [B2]; delta = sum of the NW partials, dS = P (dP - delta), dS^T
+// fragments to LDS [B3]; dQ for the wave's channels; P / dS through a wave-private tile and ds_read_b64_tr_b16 into
+// dV^T += dO^T P, dK^T += Q^T dS.  Three barriers per tile; a wave that runs ahead can only touch the other parity's Q / dO tile.
+// HBM traffic = the algorithmic minimum (Q, dO read once, dQ written once, K / V / dK / dV once per chunk).
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. the Q / dO rows requested two
+// tiles ahead and the dQ stores of the previous tile, three times per tile
+#define XW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <int D, int NSB>
+__global__ __launch_bounds__(32 * NSB) void xattn_bwd_fusedw_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ q,
+                                                                    const bf16* __restrict__ k, const bf16* __restrict__ v,
+                                                                    const float* __restrict__ lse, const uint8_t* __restrict__ valid,
+                                                                    bf16* __restrict__ dq, bf16* __restrict__ dk, bf16* __restrict__ dv,
+                                                                    float* __restrict__ dk_part, float* __restrict__ dv_part, int B,
+                                                                    int H, int T_, int S, int rows_per_chunk, int nchunk) {
+    typedef bf16 T;
+    typedef XC<T, D, NSB, 2> C;
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    constexpr int NW = NSB / 2, NT = 64 * NW;      // waves, threads
+    constexpr int DBW = C::NDB / NW;               // 16-channel blocks of dQ per wave
+    constexpr int IPW = 2 * C::NDC / NW;           // (row half, 32-channel chunk) load items per wave
+    static_assert(NSB % 2 == 0 && C::NDB % NW == 0 && (2 * C::NDC) % NW == 0 && D % 32 == 0, "fusedw: shape");
+    constexpr int LDT = C::DPAD + 16;              // Q / dO tile row stride (elements)
+    constexpr int LDP = 32 + 16;                   // wave-private P / dS tile row stride: 32 keys
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ki = (T*)smem;                              // row-major padded: row fragments (S^T) and tr16 fragments (K^T)
+    T* Vf = Ki + C::RMIMG;                         // fragment-linear row image
+    T* QG = Vf + C::ROWIMG;                        // [parity][Q | dO][32][LDT]
+    T* PD = QG + 2 * 2 * 32 * LDT;                 // [wave][P | dS][32][LDP]
+    T* DSX = PD + NW * 2 * 32 * LDP;               // [ks = wave][qt][lane][8]: dS^T B-operand fragments of every wave
+    float* dpart = (float*)(DSX + NW * 2 * 64 * 8);   // [wave][32] partial deltas
+    float* LSEt = dpart + NW * 32;                 // [parity][32] the tile's saved log-sum-exp
+    uint8_t* vld = (uint8_t*)(LSEt + 2 * 32);
+
+    const int lane = threadIdx.x & 63, x = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int vid = xcd_remap(blockIdx.x, B * H * nchunk);
+    const int bh = vid / nchunk, chunk = vid % nchunk;
+    const int b = bh / H, h = bh % H;
+    const size_t HD = (size_t)H * D;
+    const int row_begin = chunk * rows_per_chunk, row_end = min(row_begin + rows_per_chunk, T_);
+
+    const uint32_t row_bytes = (uint32_t)(HD * sizeof(T));
+    const uint32_t slab = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(dout + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dq + (size_t)b * T_ * HD + h * D, slab);
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
+
+    // this wave's pieces of a tile: item i = IPW wave + j -> row half qt = i & 1, channel chunk dc = i >> 1.  Two register sets:
+    // the tile after next is requested as soon as a set has been dropped into the shared LDS tile
+    // (the tile's 32 lse values ride along as ONE dword per lane and go through LDS like the rows: kept in registers across the loop
+    // and scaled at the top of a step, hipcc rotated them with v_mov behind s_waitcnt vmcnt(0) at the back edge -- the prefetch drained)
+    v8 qA[IPW], gA[IPW], qB[IPW], gB[IPW];
+    uint32_t lA, lB;
+    auto request = [&](int tbase, v8 (&qn)[IPW], v8 (&gn)[IPW], uint32_t& lsn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            const int i = IPW * wave + j, qt = i & 1, dc = i >> 1;
+            const int t = (tbase < row_end) ? tbase + qt * 16 + x : T_;      // past the chunk: every access falls outside the slab
+            qn[j] = buf_load8<T>(rq, row_off<T, C>(t, row_bytes, dc * 32 + g * 8));
+            gn[j] = buf_load8<T>(rg, row_off<T, C>(t, row_bytes, dc * 32 + g * 8));
+        }
+        lsn = __builtin_amdgcn_raw_buffer_load_b32(rl, (tbase < row_end && lane < 32) ? (uint32_t)(tbase + lane) * 4u : OOB, 0, 0);
+    };
+    request(row_begin, qA, gA, lA);
+    request(row_begin + 32, qB, gB, lB);
+
+    {   // K, V and the key mask in ONE memory round trip
+        const uint32_t slab_kv = (uint32_t)(((size_t)(S - 1) * HD + D) * sizeof(T));
+        const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * S * HD + h * D, slab_kv);
+        const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * S * HD + h * D, slab_kv);
+        ImageStage<T, C, NT> ks_, vs_;
+        const int tid = (int)threadIdx.x;
+        const uint8_t vraw = valid[(size_t)b * S + min(tid, S - 1)];
+        ks_.load(rk, row_bytes);
+        vs_.load(rv, row_bytes);
+        ks_.store_rowmajor(Ki);
+        vs_.store_row(Vf);
+        if (tid < C::SPAD) vld[tid] = (tid < S) ? vraw : (uint8_t)0;
+    }
+    __syncthreads();
+
+    uint32_t vlo, vhi, elo, ehi;
+    lane_key_bits<C>(vld, g, S, vlo, vhi, elo, ehi);
+    const bool any_valid = __ballot((vlo | vhi) != 0) != 0ull;
+    const float uni = 1.f / (float)S;
+    const float tie = any_valid ? 1.f : 0.5f;                 // autograd's 50/50 split at the torch.max tie
+    f32x4 bias[2];                                            // this wave's two 16-key blocks
+#pragma unroll
+    for (int sbl = 0; sbl < 2; ++sbl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[sbl][r] = bit64(vlo, vhi, (2 * wave + sbl) * 4 + r) ? 0.f : -INFINITY;
+
+    f32x4 dva[C::NDB][2], dka[C::NDB][2];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int sbl = 0; sbl < 2; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
+
+    T* Pt = PD + wave * 2 * 32 * LDP;
+    T* DSt = Pt + 32 * LDP;
+    v4 ost[2][DBW];
+    int tprev = T_;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dbl = 0; dbl < DBW; ++dbl) ost[qt][dbl] = vzero<v4>();
+    auto flush = [&]() __attribute__((always_inline)) {       // dQ of the previous tile: this wave's channel blocks
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int t = tprev + qt * 16 + x;
+            const uint32_t rb = (t < row_end) ? (uint32_t)t * row_bytes : 0x80000000u;      // (a tile past the chunk computes zeros: never stored)
+            if constexpr (DBW % 2 == 0) {
+#pragma unroll
+                for (int dbl = 0; dbl < DBW; dbl += 2) store_pair_bf16(rd, rb, wave * DBW + dbl, g, ost[qt][dbl], ost[qt][dbl + 1]);
+            } else {
+#pragma unroll
+                for (int dbl = 0; dbl < DBW; ++dbl)
+                    buf_store_v4<T>(rd, rb + (uint32_t)(((wave * DBW + dbl) * 16 + g * 4) * sizeof(T)), ost[qt][dbl]);
+            }
+        }
+    };
+
+    auto step = [&](int t0, int par, v8 (&qn)[IPW], v8 (&gn)[IPW], uint32_t& lsn) __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");                        // K / V fragments are re-read from LDS every tile (no hoisting: registers)
+        T* Qt = QG + par * 2 * 32 * LDT;
+        T* Gt = Qt + 32 * LDT;
+        flush();                                              // VMEM order per wave: stores(i-1), compute(i) ... loads(i+2)
+        tprev = t0;
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            const int i = IPW * wave + j, qt = i & 1, dc = i >> 1;
+            *(v8*)(Qt + (qt * 16 + x) * LDT + dc * 32 + g * 8) = qn[j];
+            *(v8*)(Gt + (qt * 16 + x) * LDT + dc * 32 + g * 8) = gn[j];
+        }
+        if (wave == 0 && lane < 32) ((uint32_t*)LSEt)[par * 32 + lane] = lsn;
+        XW_BARRIER();                                         // [B1] the tile's Q / dO rows are in LDS
+        request(t0 + 64, qn, gn, lsn);                        // this set's registers are free: the tile after next
+        float l2[2];                                          // rows past T: Q = dO = 0 and lse reads 0 -> finite p, dP = 0, dS = 0
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) l2[qt] = LSEt[par * 32 + qt * 16 + x] * LOG2E;
+
+        f32x4 sacc[2][2], pacc[2][2];                         // [qt][sbl]
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int sbl = 0; sbl < 2; ++sbl) { sacc[qt][sbl] = bias[sbl]; pacc[qt][sbl] = vzero<f32x4>(); }
+#pragma unroll
+        for (int dc = 0; dc < C::NDC; ++dc) {
+            v8 qf[2], gf[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                qf[qt] = *(const v8*)(Qt + (qt * 16 + x) * LDT + dc * 32 + g * 8);
+                gf[qt] = *(const v8*)(Gt + (qt * 16 + x) * LDT + dc * 32 + g * 8);
+            }
+#pragma unroll
+            for (int sbl = 0; sbl < 2; ++sbl) {
+                const v8 kf = rm_rowfrag<T, C>(Ki, 2 * wave + sbl, dc, lane);
+                const v8 vf = *(const v8*)(Vf + rf_idx<C>(2 * wave + sbl, dc, lane));
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    mma16(sacc[qt][sbl], kf, qf[qt]);
+                    mma16(pacc[qt][sbl], vf, gf[qt]);
+                }
+            }
+        }
+        // P for this wave's keys, partial delta
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const bool live = t0 + qt * 16 + x < row_end;
+            float dl = 0.f;
+#pragma unroll
+            for (int sbl = 0; sbl < 2; ++sbl) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv;
+                    if (any_valid) pv = __builtin_amdgcn_exp2f(fmaf(sacc[qt][sbl][r], LOG2E, -l2[qt]));    // masked key: exp2(-inf) = 0
+                    else pv = (live && bit64(elo, ehi, (2 * wave + sbl) * 4 + r)) ? uni : 0.f;
+                    sacc[qt][sbl][r] = pv;
+                    dl += pv * pacc[qt][sbl][r];
+                }
+                *(v4*)(Pt + (qt * 16 + x) * LDP + sbl * 16 + g * 4) = cvt4<T>(sacc[qt][sbl]);
+            }
+            dl = xg_sum(dl);
+            if (g == 0) dpart[wave * 32 + qt * 16 + x] = dl;
+        }
+        XW_BARRIER();                                         // [B2] every wave's partial delta
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float dl = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) dl += dpart[w * 32 + qt * 16 + x];
+            v4 dsb[2];
+#pragma unroll
+            for (int sbl = 0; sbl < 2; ++sbl) {
+                f32x4 d4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d4[r] = tie * sacc[qt][sbl][r] * (pacc[qt][sbl][r] - dl);
+                dsb[sbl] = cvt4<T>(d4);
+                *(v4*)(DSt + (qt * 16 + x) * LDP + sbl * 16 + g * 4) = dsb[sbl];
+            }
+            const v8 f = {dsb[0][0], dsb[0][1], dsb[0][2], dsb[0][3], dsb[1][0], dsb[1][1], dsb[1][2], dsb[1][3]};
+            *(v8*)(DSX + ((wave * 2 + qt) * 64 + lane) * 8) = f;     // B-operand fragment of key step ks = wave
+        }
+        XW_BARRIER();                                         // [B3] dS^T of all keys
+        {
+            f32x4 acc[2][DBW];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int dbl = 0; dbl < DBW; ++dbl) acc[qt][dbl] = vzero<f32x4>();
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks) {
+                v8 dsf[2];
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) dsf[qt] = *(const v8*)(DSX + ((ks * 2 + qt) * 64 + lane) * 8);
+#pragma unroll
+                for (int dbl = 0; dbl < DBW; ++dbl) {
+                    const v8 kt = rm_tfrag_tr16<C>(Ki, wave * DBW + dbl, ks, lane);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) mma16(acc[qt][dbl], kt, dsf[qt]);
+                }
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int dbl = 0; dbl < DBW; ++dbl) ost[qt][dbl] = cvt4<T>(acc[qt][dbl]);
+        }
+        // contraction over the tile's 32 rows for this wave's keys (P / dS tiles are wave-private: LDS ops of a wave run in order)
+        {
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+            const int trow = 4 * g + (x >> 2), tcol = (x & 3) * 4;
+            v8 pB[2], dsB[2];
+#pragma unroll
+            for (int sbl = 0; sbl < 2; ++sbl) {
+                const bf16* pp = Pt + trow * LDP + sbl * 16 + tcol;
+                const bf16* pd = DSt + trow * LDP + sbl * 16 + tcol;
+                const bf16x4 p0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pp);
+                const bf16x4 p1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pp + 16 * LDP));
+                const bf16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pd);
+                const bf16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pd + 16 * LDP));
+                pB[sbl] = v8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+                dsB[sbl] = v8{d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+            }
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db) {
+                const bf16* pg = Gt + trow * LDT + db * 16 + tcol;
+                const bf16* pq = Qt + trow * LDT + db * 16 + tcol;
+                const bf16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pg);
+                const bf16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pg + 16 * LDT));
+                const bf16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pq);
+                const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pq + 16 * LDT));
+                const v8 gT = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                const v8 qT = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+                for (int sbl = 0; sbl < 2; ++sbl) {
+                    mma16(dva[db][sbl], gT, pB[sbl]);
+                    mma16(dka[db][sbl], qT, dsB[sbl]);
+                }
+            }
+        }
+    };
+    // Both register sets every trip (row_end is uniform over the workgroup: every wave takes every barrier).  A chunk of an odd number
+    // of tiles runs one empty tile (loads fall outside the descriptor, p = 0, nothing stored): with the second step conditional, hipcc
+    // resolves the loop-carried lse registers with a v_mov behind s_waitcnt vmcnt(0) -- the whole prefetch drained every trip.
+    for (int t0 = row_begin; t0 < row_end; t0 += 64) {
+        step(t0, 0, qA, gA, lA);
+        step(t0 + 32, 1, qB, gB, lB);
+    }
+    flush();                                                  // the last tile's dQ
+
+#pragma unroll
+    for (int sbl = 0; sbl < 2; ++sbl) {
+        const int s_ = (2 * wave + sbl) * 16 + x;
+        if (s_ < S) {
+            if (nchunk == 1) {
+                const size_t off = ((size_t)b * S + s_) * HD + h * D + g * 4;
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) {
+                    store4<T>(dk + off + db * 16, dka[db][sbl]);
+                    store4<T>(dv + off + db * 16, dva[db][sbl]);
+                }
+            } else {
+                const size_t off = (((size_t)chunk * B + b) * S + s_) * HD + h * D + g * 4;
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) {
+                    *(f32x4*)(dk_part + off + db * 16) = dka[db][sbl];
+                    *(f32x4*)(dv_part + off + db * 16) = dva[db][sbl];
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, T* __restrict__ outp,
                                                               size_t n4, size_t chunk_stride4, int nchunk) {
@@ -992,11 +1295,18 @@ inline bool use_dkv64(int D, size_t esz) {
 inline int dkv64_keys(int D) { return D <= 64 ? 64 : 32; }
 inline constexpr bool use_fused_bwd() { return true; }
 
+// the multi-wave one-pass backward (xattn_bwd_fusedw_kernel): bf16, head_dim 64 / 128, up to 128 keys, and not the shapes the one-wave
+// fused kernel takes (D <= 64 with S <= 64)
+inline bool use_fusedw(int S, int D, size_t esz) { return esz == 2 && S <= 128 && (D == 128 || (D == 64 && S > 64)); }
+
 BwdPlan bwd_plan(int B, int H, int T, int S, int D, size_t esz = 2) {
     BwdPlan p;
-    p.nsg = use_dkv64(D, esz) ? (S + dkv64_keys(D) - 1) / dkv64_keys(D) : (S + 31) / 32;
+    const bool fw = use_fusedw(S, D, esz);
+    p.nsg = fw ? 1 : use_dkv64(D, esz) ? (S + dkv64_keys(D) - 1) / dkv64_keys(D) : (S + 31) / 32;
     long units = (long)B * H * p.nsg;
-    int nchunk = (int)((2048 + units - 1) / units);
+    // fusedw: one workgroup per CU (LDS); a chunk costs a set of fp32 dK / dV partials, so chunks only while (batch, head) pairs
+    // alone do not fill the chip
+    int nchunk = fw ? (units >= 256 ? 1 : (int)((512 + units - 1) / units)) : (int)((2048 + units - 1) / units);
     int maxchunk = (T + 63) / 64;
     if (nchunk > maxchunk) nchunk = maxchunk;
     if (nchunk < 1) nchunk = 1;
@@ -1062,6 +1372,26 @@ int launch_bwd(const void* dout, const void* q, const void* k, const void* v, co
     float* delta = (float*)(ws + p.delta_off);
     float* dkp = (float*)(ws + p.dk_off);
     float* dvp = (float*)(ws + p.dv_off);
+    if constexpr (sizeof(T) == 2 && (D == 128 || D == 64) && NSB <= 8 && !(D <= 64 && NSB <= 4)) {
+        // one pass over Q / dO with the keys split over NSB / 2 waves (p.nsg == 1: a workgroup holds all keys)
+        constexpr int NW = NSB / 2, LDT = C::DPAD + 16;
+        const size_t lds = sizeof(bf16) * (C::RMIMG + C::ROWIMG + 2 * 2 * 32 * LDT + NW * 2 * 32 * 48 + NW * 2 * 64 * 8) + (NW * 32 + 2 * 32) * sizeof(float) + C::SPAD;
+        auto kern = xattn_bwd_fusedw_kernel<D, NSB>;
+        int rc = set_lds(kern, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(B * H * p.nchunk), dim3(64 * NW), lds, st, (const bf16*)dout, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)v, lse, valid, (bf16*)dq, (bf16*)dk, (bf16*)dv, dkp, dvp, B, H, T_, S, p.rows_per_chunk, p.nchunk);
+        MMGL_CHECK_LAUNCH("xattn_bwd_fusedw");
+        if (p.nchunk > 1) {
+            size_t n4 = (size_t)B * S * H * D / 4;
+            int blocks = (int)((n4 + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3(blocks), dim3(256), 0, st, dkp, (T*)dk, n4, n4, p.nchunk);
+            hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3(blocks), dim3(256), 0, st, dvp, (T*)dv, n4, n4, p.nchunk);
+            MMGL_CHECK_LAUNCH("xattn_bwd_reduce");
+        }
+        return MMGL_OK;
+    }
     if constexpr (sizeof(T) == 2 && D <= 64 && NSB <= 4) {
         if (use_fused_bwd()) {                                // one pass over Q / dO (p.nsg == 1 here: all keys in one wave)
             constexpr int LDT = C::DPAD + 16, LDP = C::SPAD + 16;
@@ -1171,7 +1501,8 @@ extern "C" int mmgl_xattn_fwd(const void* q, const void* k, const void* v, const
 
 extern "C" size_t mmgl_xattn_bwd_workspace(int B, int H, int T, int S, int D) {
     if (B <= 0 || H <= 0 || T <= 0 || S <= 0 || D <= 0) return 0;
-    return bwd_plan(B, H, T, S, D).total;
+    const size_t a = bwd_plan(B, H, T, S, D, 2).total, b = bwd_plan(B, H, T, S, D, 4).total;     // the entry point does not know the dtype
+    return a > b ? a : b;
 }
 
 extern "C" int mmgl_xattn_bwd(const void* dout, const void* q, const void* k, const void* v, const float* lse,
@@ -1180,8 +1511,8 @@ extern "C" int mmgl_xattn_bwd(const void* dout, const void* q, const void* k, co
     int rc = check_shape("mmgl_xattn_bwd", B, H, T, S, D, dtype);
     if (rc) return rc;
     MMGL_CHECK_ARG(dout && q && k && v && lse && key_valid && dq && dk && dv && workspace, "mmgl_xattn_bwd: null pointer");
-    MMGL_CHECK_ARG(workspace_bytes >= bwd_plan(B, H, T, S, D).total, "mmgl_xattn_bwd: workspace %zu B < required %zu B",
-                   workspace_bytes, bwd_plan(B, H, T, S, D).total);
+    MMGL_CHECK_ARG(workspace_bytes >= mmgl_xattn_bwd_workspace(B, H, T, S, D), "mmgl_xattn_bwd: workspace %zu B < required %zu B",
+                   workspace_bytes, mmgl_xattn_bwd_workspace(B, H, T, S, D));
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     if (dtype == MMGL_BF16) DISPATCH_D(launch_bwd, bf16, dout, q, k, v, lse, key_valid, dq, dk, dv, ws, B, H, T, S, st);

@@ -35,6 +35,12 @@ CASES = [  # B, H, T, S, D
     (4, 32, 640, 64, 64),    # config 3: OPT-1.3B, 16 neighbors
     (2, 32, 2176, 128, 128), # config 5: Llama-2-7B dims, 32 neighbors
     (3, 3, 77, 200, 64),     # S > 128 path, odd sizes
+    # the multi-wave one-pass backward (bf16: xattn_bwd_fusedw_kernel; fp32 runs the two-kernel path on the same shapes)
+    (3, 4, 100, 128, 128),   # 4 waves, ragged T, two T-chunks (fp32 dK / dV partials), a fully masked sample
+    (8, 32, 96, 128, 128),   # >= 256 (batch, head) pairs: one chunk, dK / dV written once in bf16
+    (2, 4, 77, 40, 128),     # D = 128, S <= 64: 2 waves, ragged S
+    (3, 2, 90, 20, 128),     # D = 128, S <= 32: 1 wave
+    (3, 4, 130, 100, 64),    # D = 64, 64 < S <= 128: 4 waves, one 16-channel dQ block per wave
 ]
 
 

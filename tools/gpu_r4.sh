@@ -17,6 +17,10 @@ case $what in
     MMGL_GEMM_DYNAMIC=2 python bench.py --no-cpu-baseline > $out/bench_dyn.json 2> $out/bench_dyn.err
     python bench.py --no-cpu-baseline --config opt-125m > $out/bench125_static.json 2>> $out/bench_static.err
     MMGL_GEMM_DYNAMIC=2 python bench.py --no-cpu-baseline --config opt-125m > $out/bench125_dyn.json 2>> $out/bench_dyn.err;;
+  xattn)
+    python -m pytest tests/test_xattn_gpu.py tests/test_llama_gpu.py -q -x 2>&1 | tail -30 > $out/tests_xattn.log
+    python tools/bench_xattn.py llama > $out/bench_xattn_llama.txt 2>&1
+    python bench.py --config llama-2-7b --no-cpu-baseline > $out/bench_llama.json 2> $out/bench_llama.err;;
   bench)
     python bench.py > $out/bench.json 2> $out/bench.err;;
   *) echo "unknown $what";;
