@@ -1005,9 +1005,8 @@ __global__ __launch_bounds__(32 * NSB) void xattn_bwd_fusedw_kernel(const bf16* 
     constexpr int LDT = C::DPAD + 16;              // Q / dO tile row stride (elements)
     constexpr int LDP = 32 + 16;                   // wave-private P / dS tile row stride: 32 keys
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Ki = (T*)smem;                              // row-major padded: row fragments (S^T) and tr16 fragments (K^T)
-    T* Vf = Ki + C::RMIMG;                         // fragment-linear row image
-    T* QG = Vf + C::ROWIMG;                        // [parity][Q | dO][32][LDT]
+    T* Ki = (T*)smem;                              // row-major padded K: read ONCE, by ds_read_b64_tr_b16, for the K^T fragments below
+    T* QG = Ki + C::RMIMG;                         // [parity][Q | dO][32][LDT]
     T* PD = QG + 2 * 2 * 32 * LDT;                 // [wave][P | dS][32][LDP]
     T* DSX = PD + NW * 2 * 32 * LDP;               // [ks = wave][qt][lane][8]: dS^T B-operand fragments of every wave
     float* dpart = (float*)(DSX + NW * 2 * 64 * 8);   // [wave][32] partial deltas
@@ -1048,20 +1047,45 @@ __global__ __launch_bounds__(32 * NSB) void xattn_bwd_fusedw_kernel(const bf16* 
     request(row_begin, qA, gA, lA);
     request(row_begin + 32, qB, gB, lB);
 
-    {   // K, V and the key mask in ONE memory round trip
+    // K and V of this wave's keys live in REGISTERS for the whole chunk (one wave per SIMD: the register file is there, the LDS port
+    // is the scarce resource -- re-reading them every tile was 96 of the 312 KiB a tile moved through LDS):
+    //   kf / vf [sbl][dc]  row fragments (A operands of S^T = K Q^T, dP^T = V dO^T), straight from global memory in fragment layout;
+    //   kt [dbl][ks]       K^T fragments of this wave's dQ channels over ALL keys, by transposed reads of a row-major K image
+    v8 kf[2][C::NDC], vf[2][C::NDC], kt[DBW][C::NKS];
+    {
         const uint32_t slab_kv = (uint32_t)(((size_t)(S - 1) * HD + D) * sizeof(T));
         const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * S * HD + h * D, slab_kv);
         const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * S * HD + h * D, slab_kv);
-        ImageStage<T, C, NT> ks_, vs_;
+        ImageStage<T, C, NT> ks_;
         const int tid = (int)threadIdx.x;
         const uint8_t vraw = valid[(size_t)b * S + min(tid, S - 1)];
         ks_.load(rk, row_bytes);
-        vs_.load(rv, row_bytes);
+#pragma unroll
+        for (int sbl = 0; sbl < 2; ++sbl)
+#pragma unroll
+            for (int dc = 0; dc < C::NDC; ++dc) {            // rows past S fall outside the descriptor: zero fragments
+                const uint32_t off = row_off<T, C>((2 * wave + sbl) * 16 + x, row_bytes, dc * 32 + g * 8);
+                kf[sbl][dc] = buf_load8<T>(rk, off);
+                vf[sbl][dc] = buf_load8<T>(rv, off);
+            }
         ks_.store_rowmajor(Ki);
-        vs_.store_row(Vf);
         if (tid < C::SPAD) vld[tid] = (tid < S) ? vraw : (uint8_t)0;
     }
     __syncthreads();
+#pragma unroll
+    for (int dbl = 0; dbl < DBW; ++dbl)
+#pragma unroll
+        for (int ks = 0; ks < C::NKS; ++ks) kt[dbl][ks] = rm_tfrag_tr16<C>(Ki, wave * DBW + dbl, ks, lane);
+    // (a load issued before a loop and first used inside it stays pending in hipcc's scoreboard at the loop header: every trip would
+    // wait for it with counts that also drain the prefetch -- have the fragments read once here)
+#pragma unroll
+    for (int sbl = 0; sbl < 2; ++sbl)
+#pragma unroll
+        for (int dc = 0; dc < C::NDC; ++dc) asm volatile("" ::"v"(kf[sbl][dc]), "v"(vf[sbl][dc]));
+#pragma unroll
+    for (int dbl = 0; dbl < DBW; ++dbl)
+#pragma unroll
+        for (int ks = 0; ks < C::NKS; ++ks) asm volatile("" ::"v"(kt[dbl][ks]));
 
     uint32_t vlo, vhi, elo, ehi;
     lane_key_bits<C>(vld, g, S, vlo, vhi, elo, ehi);
@@ -1080,8 +1104,6 @@ __global__ __launch_bounds__(32 * NSB) void xattn_bwd_fusedw_kernel(const bf16* 
 #pragma unroll
         for (int sbl = 0; sbl < 2; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
 
-    T* Pt = PD + wave * 2 * 32 * LDP;
-    T* DSt = Pt + 32 * LDP;
     v4 ost[2][DBW];
     int tprev = T_;
 #pragma unroll
@@ -1104,10 +1126,51 @@ __global__ __launch_bounds__(32 * NSB) void xattn_bwd_fusedw_kernel(const bf16* 
         }
     };
 
+    // dV^T += dO^T P, dK^T += Q^T dS over the 32 rows of the tile of parity `par` for this wave's keys: P / dS from the wave-private
+    // tiles (LDS ops of a wave run in order), dO^T / Q^T from the shared tile, all by ds_read_b64_tr_b16.  (Run one tile LATE, inside the
+    // next tile's first segment, with parity-double-buffered P / dS tiles: measured 162.9 against 158.4 us -- no gain, not kept.)
+    auto contract = [&](int par) __attribute__((always_inline)) {
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const T* Qt = QG + par * 2 * 32 * LDT;
+        const T* Gt = Qt + 32 * LDT;
+        const T* Pt = PD + wave * 2 * 32 * LDP;
+        const T* DSt = Pt + 32 * LDP;
+        const int trow = 4 * g + (x >> 2), tcol = (x & 3) * 4;
+        v8 pB[2], dsB[2];
+#pragma unroll
+        for (int sbl = 0; sbl < 2; ++sbl) {
+            const bf16* pp = Pt + trow * LDP + sbl * 16 + tcol;
+            const bf16* pd = DSt + trow * LDP + sbl * 16 + tcol;
+            const bf16x4 p0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pp);
+            const bf16x4 p1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pp + 16 * LDP));
+            const bf16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pd);
+            const bf16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pd + 16 * LDP));
+            pB[sbl] = v8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+            dsB[sbl] = v8{d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+        }
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) {
+            const bf16* pg = Gt + trow * LDT + db * 16 + tcol;
+            const bf16* pq = Qt + trow * LDT + db * 16 + tcol;
+            const bf16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pg);
+            const bf16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pg + 16 * LDT));
+            const bf16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pq);
+            const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pq + 16 * LDT));
+            const v8 gT = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+            const v8 qT = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+            for (int sbl = 0; sbl < 2; ++sbl) {
+                mma16(dva[db][sbl], gT, pB[sbl]);
+                mma16(dka[db][sbl], qT, dsB[sbl]);
+            }
+        }
+    };
+
     auto step = [&](int t0, int par, v8 (&qn)[IPW], v8 (&gn)[IPW], uint32_t& lsn) __attribute__((always_inline)) {
-        asm volatile("" ::: "memory");                        // K / V fragments are re-read from LDS every tile (no hoisting: registers)
         T* Qt = QG + par * 2 * 32 * LDT;
         T* Gt = Qt + 32 * LDT;
+        T* Pt = PD + wave * 2 * 32 * LDP;
+        T* DSt = Pt + 32 * LDP;
         flush();                                              // VMEM order per wave: stores(i-1), compute(i) ... loads(i+2)
         tprev = t0;
 #pragma unroll
@@ -1137,15 +1200,12 @@ __global__ __launch_bounds__(32 * NSB) void xattn_bwd_fusedw_kernel(const bf16* 
                 gf[qt] = *(const v8*)(Gt + (qt * 16 + x) * LDT + dc * 32 + g * 8);
             }
 #pragma unroll
-            for (int sbl = 0; sbl < 2; ++sbl) {
-                const v8 kf = rm_rowfrag<T, C>(Ki, 2 * wave + sbl, dc, lane);
-                const v8 vf = *(const v8*)(Vf + rf_idx<C>(2 * wave + sbl, dc, lane));
+            for (int sbl = 0; sbl < 2; ++sbl)
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
-                    mma16(sacc[qt][sbl], kf, qf[qt]);
-                    mma16(pacc[qt][sbl], vf, gf[qt]);
+                    mma16(sacc[qt][sbl], kf[sbl][dc], qf[qt]);
+                    mma16(pacc[qt][sbl], vf[sbl][dc], gf[qt]);
                 }
-            }
         }
         // P for this wave's keys, partial delta
 #pragma unroll
@@ -1198,50 +1258,16 @@ __global__ __launch_bounds__(32 * NSB) void xattn_bwd_fusedw_kernel(const bf16* 
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) dsf[qt] = *(const v8*)(DSX + ((ks * 2 + qt) * 64 + lane) * 8);
 #pragma unroll
-                for (int dbl = 0; dbl < DBW; ++dbl) {
-                    const v8 kt = rm_tfrag_tr16<C>(Ki, wave * DBW + dbl, ks, lane);
+                for (int dbl = 0; dbl < DBW; ++dbl)
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) mma16(acc[qt][dbl], kt, dsf[qt]);
-                }
+                    for (int qt = 0; qt < 2; ++qt) mma16(acc[qt][dbl], kt[dbl][ks], dsf[qt]);
             }
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
                 for (int dbl = 0; dbl < DBW; ++dbl) ost[qt][dbl] = cvt4<T>(acc[qt][dbl]);
         }
-        // contraction over the tile's 32 rows for this wave's keys (P / dS tiles are wave-private: LDS ops of a wave run in order)
-        {
-            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-            const int trow = 4 * g + (x >> 2), tcol = (x & 3) * 4;
-            v8 pB[2], dsB[2];
-#pragma unroll
-            for (int sbl = 0; sbl < 2; ++sbl) {
-                const bf16* pp = Pt + trow * LDP + sbl * 16 + tcol;
-                const bf16* pd = DSt + trow * LDP + sbl * 16 + tcol;
-                const bf16x4 p0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pp);
-                const bf16x4 p1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pp + 16 * LDP));
-                const bf16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pd);
-                const bf16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pd + 16 * LDP));
-                pB[sbl] = v8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-                dsB[sbl] = v8{d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-            }
-#pragma unroll
-            for (int db = 0; db < C::NDB; ++db) {
-                const bf16* pg = Gt + trow * LDT + db * 16 + tcol;
-                const bf16* pq = Qt + trow * LDT + db * 16 + tcol;
-                const bf16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pg);
-                const bf16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pg + 16 * LDT));
-                const bf16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pq);
-                const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pq + 16 * LDT));
-                const v8 gT = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-                const v8 qT = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-#pragma unroll
-                for (int sbl = 0; sbl < 2; ++sbl) {
-                    mma16(dva[db][sbl], gT, pB[sbl]);
-                    mma16(dka[db][sbl], qT, dsB[sbl]);
-                }
-            }
-        }
+        contract(par);
     };
     // Both register sets every trip (row_end is uniform over the workgroup: every wave takes every barrier).  A chunk of an odd number
     // of tiles runs one empty tile (loads fall outside the descriptor, p = 0, nothing stored): with the second step conditional, hipcc
@@ -1375,7 +1401,7 @@ int launch_bwd(const void* dout, const void* q, const void* k, const void* v, co
     if constexpr (sizeof(T) == 2 && (D == 128 || D == 64) && NSB <= 8 && !(D <= 64 && NSB <= 4)) {
         // one pass over Q / dO with the keys split over NSB / 2 waves (p.nsg == 1: a workgroup holds all keys)
         constexpr int NW = NSB / 2, LDT = C::DPAD + 16;
-        const size_t lds = sizeof(bf16) * (C::RMIMG + C::ROWIMG + 2 * 2 * 32 * LDT + NW * 2 * 32 * 48 + NW * 2 * 64 * 8) + (NW * 32 + 2 * 32) * sizeof(float) + C::SPAD;
+        const size_t lds = sizeof(bf16) * (C::RMIMG + 2 * 2 * 32 * LDT + NW * 2 * 32 * 48 + NW * 2 * 64 * 8) + (NW * 32 + 2 * 32) * sizeof(float) + C::SPAD;
         auto kern = xattn_bwd_fusedw_kernel<D, NSB>;
         int rc = set_lds(kern, lds);
         if (rc) return rc;

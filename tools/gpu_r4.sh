@@ -21,6 +21,8 @@ case $what in
     python -m pytest tests/test_xattn_gpu.py tests/test_llama_gpu.py -q -x 2>&1 | tail -30 > $out/tests_xattn.log
     python tools/bench_xattn.py llama > $out/bench_xattn_llama.txt 2>&1
     python bench.py --config llama-2-7b --no-cpu-baseline > $out/bench_llama.json 2> $out/bench_llama.err;;
+  xattn_pmc)
+    bash tools/pmc_xattn.sh 8 llama > /dev/null 2>&1; cp gpurun_out/pmc_xattn_B8llama.txt $out/;;
   bench)
     python bench.py > $out/bench.json 2> $out/bench.err;;
   *) echo "unknown $what";;

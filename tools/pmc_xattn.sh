@@ -3,14 +3,15 @@
 # FETCH_SIZE and WRITE_SIZE in SEPARATE passes, kernel-trace only.  Calibration pass: a 256 MiB torch copy (16 B/lane).
 # usage: tools/pmc_xattn.sh <B>      (writes gpurun_out/pmc_xattn_B<B>.txt)
 B=${1:-8}
+SHAPE=${2:-}
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-out=gpurun_out/pmc_xattn_B$B.txt
+out=gpurun_out/pmc_xattn_B$B$SHAPE.txt
 : > $out
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
-  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$ctr -o p -- python tools/pmc_target.py $B > /tmp/pmc_$ctr.log 2>&1
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$ctr -o p -- python tools/pmc_target.py $B $SHAPE > /tmp/pmc_$ctr.log 2>&1
   python - "$ctr" >> $out <<'PY'
 import csv, glob, sys, collections
 ctr = sys.argv[1]
