@@ -23,6 +23,10 @@ case $what in
     python bench.py --config llama-2-7b --no-cpu-baseline > $out/bench_llama.json 2> $out/bench_llama.err;;
   xattn_pmc)
     bash tools/pmc_xattn.sh 8 llama > /dev/null 2>&1; cp gpurun_out/pmc_xattn_B8llama.txt $out/;;
+  sa)
+    timeout 900 python -m pytest tests/test_selfattn_gpu.py -q -x 2>&1 | tail -15 > $out/tests_sa.log
+    timeout 600 bash tools/gpu_variants.sh python tools/bench_selfattn.py 64 > $out/bench_sa_variants.txt 2>&1
+    timeout 600 bash tools/pmc_mem.sh "sa32" $out/pmc_sa32_mem.txt -- python tools/probes/selfattn_one.py 64 > /dev/null 2>&1;;
   bench)
     python bench.py > $out/bench.json 2> $out/bench.err;;
   *) echo "unknown $what";;
