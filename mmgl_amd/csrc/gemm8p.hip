@@ -717,8 +717,10 @@ void gemm8p_plan(int M, int N, int K, int* direct, int* nsplit) {
         return;
     }
     constexpr int hybrid = 3;                             // smallest split count worth it
+    // up to 12 whole rounds (round 4: Llama's 17408-row outputs with N = 4096 are 1088 tiles = 4.25 rounds -- o_proj, down_proj and,
+    // in the backward pass, the dgrads of q|k|v and gate|up, K up to 22016: a fifth round at a quarter of the chip cost 15 % of each)
     const int G = p8_num_cu(), rounds = tiles / G, r = tiles % G;
-    if (!hybrid || rounds < 1 || rounds > 3 || r == 0) return;
+    if (!hybrid || rounds < 1 || rounds > 12 || r == 0) return;
     int s = G / r;
     if (s > 8) s = 8;
     if (s > units / 4) s = units / 4;                     // at least four 128-wide K steps per item

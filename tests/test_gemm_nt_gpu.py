@@ -50,6 +50,7 @@ CASES = [
     (4700, 8192, 2048, 3, True, False, False, 1.0),      # two whole rounds (4096 rows) + a 604-row tail
     (2570, 8200, 2048, 0, True, True, True, 0.5),        # the same with ragged last tile row / column (363 tiles), zmask + residual in the finish kernel
     (2560, 8192, 4096, 3, False, False, False, 1.0),     # the row split at K = 4096, quick-GELU
+    (17408, 4096, 4096, 0, True, True, False, 1.0),      # config 5 (8 x 2176 rows): 1088 tiles = 4.25 rounds -> 4 whole rounds + 64 tiles as 4 K splits each
     (1024, 512, 256, 1, True, False, False, 1.0),        # few tiles: the 128x128 kernel (csrc/gemm_mid.hip)
     (300, 96, 64, 2, True, True, True, 2.0),             # tiny, one K step, ragged rows and columns, every epilogue stage
     (2560, 2048, 2048, 0, True, True, False, 1.0),       # out_proj at the reference's batch of 4: 320 tiles of 128x128, two workgroups per CU

@@ -27,6 +27,9 @@ case $what in
     timeout 900 python -m pytest tests/test_selfattn_gpu.py -q -x 2>&1 | tail -15 > $out/tests_sa.log
     timeout 600 bash tools/gpu_variants.sh python tools/bench_selfattn.py 64 > $out/bench_sa_variants.txt 2>&1
     timeout 600 bash tools/pmc_mem.sh "sa32" $out/pmc_sa32_mem.txt -- python tools/probes/selfattn_one.py 64 > /dev/null 2>&1;;
+  llama)
+    timeout 1200 python -m pytest tests/test_gemm_nt_gpu.py tests/test_llama_gpu.py -q -x 2>&1 | tail -8 > $out/tests_llama.log
+    python bench.py --config llama-2-7b --no-cpu-baseline > $out/bench_llama.json 2> $out/bench_llama.err;;
   bench)
     python bench.py > $out/bench.json 2> $out/bench.err;;
   *) echo "unknown $what";;
