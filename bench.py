@@ -40,7 +40,7 @@ CONFIGS = {
                      metric="train samples/sec (OPT-1.3B flamingo, 16 neighbors)"),
     "opt-125m": dict(kind="flamingo", lm=dict(vocab_size=50272, hidden_size=768, num_attention_heads=12, ffn_dim=3072, num_hidden_layers=12,
                                               max_position_embeddings=2048, word_embed_proj_dim=768), nt=2, ni=2, wise=3,
-                     model_name="facebook/mpt-125m", batch=64, lin=512, lout=128, vocab=50272,
+                     model_name="facebook/mpt-125m", batch=102, lin=512, lout=128, vocab=50272,
                      metric="train samples/sec (OPT-125m flamingo, 4 neighbors)"),
     # configs[3]: LoRA r=16 on q_proj / v_proj of OPT-1.3B, neighbors concatenated into the sequence (T = 640 + 64), lm_head trainable
     "opt-1.3b-lora": dict(kind="lora", lm=dict(vocab_size=50272, hidden_size=2048, num_attention_heads=32, ffn_dim=8192, num_hidden_layers=24,
