@@ -341,6 +341,29 @@ int mmgl_activation_fwd(const void* x, void* y, size_t n, int act, int dtype, vo
  * gradient without a host sync. */
 int mmgl_scale(const void* x, const float* scale, void* y, size_t n, int dtype, void* stream);
 
+/* ---- gradient exchange over RCCL (xGMI) --------------------------------------------------------------------------------
+ * replaces: the NCCL process group behind the reference's data-parallel wiring -- language_modelling/run_generation.py:283
+ *   (dist.init_process_group("nccl")), :317-319 (DistributedDataParallel: the constructor's parameter broadcast and the bucketed
+ *   gradient all-reduce of every backward pass, :485), language_modelling/utils.py:113-118 (AverageMeter.all_reduce),
+ *   run_generation.py:608-616 (all_gather of the evaluation predictions).  One process per GPU; single node, like the reference.
+ *   mmgl_comm_unique_id: rank 0 fills 128 bytes (ncclUniqueId) and hands them to the other ranks out of band (file, socket, env).
+ *   mmgl_comm_init: every rank, with its HIP device current, joins the communicator of that id; *comm is the handle.
+ *   mmgl_allreduce_sum: buf[count] <- sum over ranks, in place, on `stream` (averaging: fold 1/world into mmgl_adamw_step's
+ *     grad_scale).  mmgl_allgather: out[world * count_per_rank] <- every rank's in[count_per_rank], rank order.
+ *   mmgl_broadcast: buf[count] of `root` to every rank (DDP's constructor broadcast).  mmgl_comm_destroy: frees the handle.
+ *   dtype: MMGL_F32, MMGL_BF16 or MMGL_COMM_I64 (token ids of the eval gather).  Collectives of one communicator must be issued
+ *   in the same order on every rank (mmgl_amd.distributed.DataParallelEngine issues its buckets in index order).
+ *   RCCL is resolved at run time (the librccl.so the process already holds, else the system's); without it these six return
+ *   MMGL_ERR_UNSUPPORTED and every other entry point is unaffected.  mmgl_amd's own trainer reaches the same RCCL through
+ *   torch.distributed's "nccl" backend; these are the calls for a host program that has no torch.distributed. */
+enum { MMGL_COMM_I64 = 2 };
+int mmgl_comm_unique_id(void* out128);
+int mmgl_comm_init(int rank, int world, const void* unique_id, void** comm);
+int mmgl_allreduce_sum(void* comm, void* buf, size_t count, int dtype, void* stream);
+int mmgl_allgather(void* comm, const void* in, void* out, size_t count_per_rank, int dtype, void* stream);
+int mmgl_broadcast(void* comm, void* buf, size_t count, int dtype, int root, void* stream);
+int mmgl_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

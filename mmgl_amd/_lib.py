@@ -11,7 +11,7 @@ import torch  # imported first on purpose: the .so must bind to the HIP runtime 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMGL_LIB_PATH") or os.path.join(_HERE, "libmmgl_hip.so")     # override: timing experiments with ablated builds
 
-ABI_VERSION = 102         # = mmgl_version() of the library this binding was written against (csrc/lib.hip)
+ABI_VERSION = 103         # = mmgl_version() of the library this binding was written against (csrc/lib.hip)
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
 _ERR_INVALID, _ERR_UNSUPPORTED, _ERR_HIP = 1, 2, 3
@@ -77,6 +77,12 @@ SIGNATURES = {
     "mmgl_rope": (I, [P, P, P, Z, I, I, I, I, I, I, I, I, P]),
     "mmgl_swiglu_fwd": (I, [P, P, Z, I, I, P]),
     "mmgl_swiglu_bwd": (I, [P, P, P, Z, I, I, P]),
+    "mmgl_comm_unique_id": (I, [P]),
+    "mmgl_comm_init": (I, [I, I, P, ctypes.POINTER(ctypes.c_void_p)]),
+    "mmgl_allreduce_sum": (I, [P, P, Z, I, P]),
+    "mmgl_allgather": (I, [P, P, P, Z, I, P]),
+    "mmgl_broadcast": (I, [P, P, Z, I, I, P]),
+    "mmgl_comm_destroy": (I, [P]),
 }
 
 _lib = None

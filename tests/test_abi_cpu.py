@@ -57,6 +57,13 @@ def test_argument_validation_error_codes():
         _lib.check(2, "x")
     with pytest.raises(RuntimeError):
         _lib.check(3, "x")
+    # the gradient-exchange entry points validate before they touch RCCL; the unique id needs no device
+    assert L.mmgl_comm_init(2, 2, None, None) == 1 and L.mmgl_allreduce_sum(None, None, 4, 0, None) == 1
+    assert L.mmgl_comm_destroy(None) == 0
+    uid = (ctypes.c_char * 128)()
+    rc = L.mmgl_comm_unique_id(uid)
+    assert rc in (0, 2), L.mmgl_last_error()             # 2: no librccl.so on this machine
+    assert rc != 0 or any(bytes(uid))
 
 
 def test_no_cpu_fallback():

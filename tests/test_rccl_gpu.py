@@ -101,3 +101,80 @@ def test_bench_self_launch_refuses_a_mismatched_world(monkeypatch):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
                        text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_c_abi_comm_one_rank_over_rccl():
+    """include/mmgl_hip.h's gradient-exchange entry points (mmgl_comm_unique_id / _init / mmgl_allreduce_sum / mmgl_allgather /
+    mmgl_broadcast / mmgl_comm_destroy: the reference's NCCL process group, run_generation.py:283, 317-319, 608-616) driven through
+    ctypes on the one GPU of the box: a 1-rank RCCL communicator, collectives on torch's current stream.  With one rank a sum, a
+    gather and a broadcast are the identity: values must come back bit-identical, for every dtype the ABI admits."""
+    import ctypes
+    from mmgl_amd import _lib
+    L = _lib.lib()
+    torch.cuda.set_device(0)
+    uid = (ctypes.c_char * 128)()
+    _lib.check(L.mmgl_comm_unique_id(uid), "unique_id")
+    comm = ctypes.c_void_p()
+    _lib.check(L.mmgl_comm_init(0, 1, uid, ctypes.byref(comm)), "init")
+    assert comm.value
+    st = _lib.stream_ptr()
+    try:
+        for dt, code in ((torch.float32, _lib.F32), (torch.bfloat16, _lib.BF16), (torch.int64, 2)):
+            x = (torch.randn(100003, device="cuda") * 50).to(dt)
+            want = x.clone()
+            _lib.check(L.mmgl_allreduce_sum(comm, _lib.ptr(x), x.numel(), code, st), "allreduce")
+            out = torch.empty_like(x)
+            _lib.check(L.mmgl_allgather(comm, _lib.ptr(x), _lib.ptr(out), x.numel(), code, st), "allgather")
+            _lib.check(L.mmgl_broadcast(comm, _lib.ptr(x), x.numel(), code, 0, st), "broadcast")
+            torch.cuda.synchronize()
+            assert torch.equal(x, want) and torch.equal(out, want), dt
+        with pytest.raises(ValueError):
+            _lib.check(L.mmgl_allreduce_sum(comm, _lib.ptr(x), x.numel(), 7, st), "bad dtype")
+    finally:
+        _lib.check(L.mmgl_comm_destroy(comm), "destroy")
+
+
+_COMM_WORKER = r"""
+import ctypes, os, sys, time, torch
+sys.path.insert(0, sys.argv[1])
+from mmgl_amd import _lib
+rank, world, path = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+torch.cuda.set_device(rank)
+L = _lib.lib()
+uid = (ctypes.c_char * 128)()
+if rank == 0:
+    _lib.check(L.mmgl_comm_unique_id(uid), "uid")
+    open(path + ".tmp", "wb").write(bytes(uid)); os.rename(path + ".tmp", path)
+else:
+    while not os.path.exists(path): time.sleep(0.05)
+    ctypes.memmove(uid, open(path, "rb").read(), 128)
+comm = ctypes.c_void_p()
+_lib.check(L.mmgl_comm_init(rank, world, uid, ctypes.byref(comm)), "init")
+st = _lib.stream_ptr()
+x = torch.full((4096,), float(rank + 1), device="cuda", dtype=torch.bfloat16)
+_lib.check(L.mmgl_allreduce_sum(comm, _lib.ptr(x), x.numel(), _lib.BF16, st), "allreduce")
+g = torch.empty(world * 8, device="cuda", dtype=torch.int64)
+mine = torch.arange(8, device="cuda") + 100 * rank
+_lib.check(L.mmgl_allgather(comm, _lib.ptr(mine), _lib.ptr(g), 8, 2, st), "allgather")
+b = torch.full((16,), float(rank), device="cuda")
+_lib.check(L.mmgl_broadcast(comm, _lib.ptr(b), 16, _lib.F32, 1, st), "broadcast")
+torch.cuda.synchronize()
+assert float(x[0]) == world * (world + 1) / 2 and (x == x[0]).all()
+assert g.tolist() == [i + 100 * r for r in range(world) for i in range(8)]
+assert (b == 1.0).all()
+_lib.check(L.mmgl_comm_destroy(comm), "destroy")
+print("ok", rank)
+"""
+
+
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs >= 2 GPUs")
+def test_c_abi_comm_two_ranks_over_rccl(tmp_path):
+    """The same entry points with two ranks on two GPUs (unique id handed over through a file): sums, gathers, broadcast."""
+    script = tmp_path / "w.py"
+    script.write_text(_COMM_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", str(tmp_path / "uid")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env) for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0 and "ok" in out, err[-2000:]
