@@ -114,6 +114,51 @@ def test_xattn_properties_full_size():
     assert torch.equal(o1, ops.xattn_core(q, k, v, valid, H))
 
 
+def test_xattn_bwd_properties_config5_full_size():
+    """Size-independent properties of the multi-wave one-pass backward at BASELINE config 5's full size (B = 8, H = 32, T = 2176,
+    S = 128, D = 128: too big for the CPU oracle in seconds): (i) determinism -- two launches bit-equal; (ii) keys that are masked
+    receive EXACTLY zero dK and dV, and their contents do not influence any gradient; (iii) exact linearity in the upstream gradient
+    for a power-of-two factor (scaling dO by 4 scales dP, delta, dS and all three gradients by 4 with the same roundings);
+    (iv) dQ of a sample depends on that sample only."""
+    from mmgl_amd import ops
+    B, H, T, S, D = 8, 32, 2176, 128, 128
+    gen = torch.Generator().manual_seed(55)
+    d = H * D
+    q = (torch.randn(B, T, d, generator=gen) * 0.15).bfloat16().cuda()
+    k = torch.randn(B, S, d, generator=gen).bfloat16().cuda()
+    v = torch.randn(B, S, d, generator=gen).bfloat16().cuda()
+    w = torch.randn(B, T, d, generator=gen).bfloat16().cuda()
+    valid = torch.rand(B, S, generator=gen) > 0.3
+    valid[:, 0] = True
+    valid = valid.cuda()
+
+    def grads(q_, k_, v_, w_):
+        qq, kk, vv = (t.clone().requires_grad_() for t in (q_, k_, v_))
+        out = ops.xattn_core(qq, kk, vv, valid, H)
+        out.backward(w_)
+        return qq.grad, kk.grad, vv.grad
+
+    dq, dk, dv = grads(q, k, v, w)
+    dq2, dk2, dv2 = grads(q, k, v, w)
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)                 # (i)
+    assert torch.isfinite(dq).all() and torch.isfinite(dk).all() and torch.isfinite(dv).all()
+    assert float(dk[~valid].abs().max()) == 0.0 and float(dv[~valid].abs().max()) == 0.0           # (ii)
+    assert float(dk[valid].abs().max()) > 0 and float(dv[valid].abs().max()) > 0
+    k3, v3 = k.clone(), v.clone()
+    k3[~valid] = 77.0
+    v3[~valid] = -55.0
+    dq3, dk3, dv3 = grads(q, k3, v3, w)
+    assert torch.equal(dq, dq3) and torch.equal(dk, dk3) and torch.equal(dv, dv3)
+    dq4, dk4, dv4 = grads(q, k, v, w * 4)                                                          # (iii)
+    assert torch.equal(dq4, dq * 4) and torch.equal(dk4, dk * 4) and torch.equal(dv4, dv * 4)
+    q5, w5 = q.clone(), w.clone()                                                                  # (iv)
+    q5[1:] = q5[1:].flip(1)
+    w5[1:] = w5[1:] * 0.5
+    dq5, dk5, dv5 = grads(q5, k, v, w5)
+    assert torch.equal(dq5[0], dq[0]) and torch.equal(dk5[0], dk[0]) and torch.equal(dv5[0], dv[0])
+    assert not torch.equal(dq5[1], dq[1])
+
+
 def test_xattn_errors():
     from mmgl_amd import ops
     q = torch.randn(2, 8, 48, device="cuda")
