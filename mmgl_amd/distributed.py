@@ -141,6 +141,7 @@ class DataParallelEngine:
         # collective on gradient memory is ever issued.  A diagnostic after the fact (rounds 2-3) could only fire once RCCL had
         # already matched mismatched all-reduces.
         self.launch_order: List[int] = []
+        self.last_launch_order: List[int] = []      # of the last finished exchange (tests, diagnostics)
         self._next_launch = 0
         if self.exchange:
             self._check_bucket_layout()
