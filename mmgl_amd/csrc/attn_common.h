@@ -4,9 +4,6 @@
 #include "common.h"
 #include <stdlib.h>
 
-#ifndef MMGL_XATTN_ABLATE
-#define MMGL_XATTN_ABLATE 0      // timing experiments only (tools/bench_xattn.py); never set in a shipped build
-#endif
 #ifndef MMGL_XATTN_HOIST_MAX
 #define MMGL_XATTN_HOIST_MAX 16
 #endif

@@ -111,12 +111,6 @@ __device__ __forceinline__ int p8_lane() {
     return l;
 }
 
-#ifndef P8_RELAX
-#define P8_RELAX 0                   // 1: relaxed vmcnt in a tile's first five phases (peeled first K-tile pair); measured neutral, kept for experiments
-#endif
-#ifndef P8_REALIGN
-#define P8_REALIGN 1                 // one extra barrier per wave group and tile: both groups' epilogues between the same two barriers
-#endif
 // Cache policy bits of the output stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  nt + sc1: the output tile is streamed out without
 // staying in the L2 that holds the operand tiles the other workgroups of the XCD are about to read -- 40960x8192x2048 1029 -> 920 us
 // (1336 -> 1494 TF), 6144 columns 754 -> 706, 2048 columns 269 -> 253, the seven shapes of tools/probes/gemm_step_shapes.py 3494 -> 3299 us;
@@ -140,22 +134,9 @@ __device__ __forceinline__ int p8_lane() {
 #ifndef P8_TRACE
 #define P8_TRACE 0                   // timing experiments only: clock stamps of workgroup 0 into P8Args::trace
 #endif
-#ifndef P8_ABLATE
-#define P8_ABLATE 0                  // timing experiments only (1: no epilogue, 2: epilogue without its stores); never set in a shipped build
-#endif
 #define P8_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define P8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define P8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-// after the barrier that opens an MFMA cluster: wait for every fragment (1) or let hipcc's own counted lgkmcnt waits release the
-// MFMAs fragment by fragment (0: the first MFMAs start while the last ds_reads are still in flight)
-#ifndef P8_WAIT_ALL_FRAGS
-#define P8_WAIT_ALL_FRAGS 0
-#endif
-#if P8_WAIT_ALL_FRAGS
-#define P8_LGKM_PHASE() P8_LGKM0()
-#else
-#define P8_LGKM_PHASE() (void)0
-#endif
 
 template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel(P8Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -450,11 +431,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
                             ob[e] &= mk;
                         }
                     }
-#if P8_ABLATE & 2
-                    asm volatile("" :: "v"(ob));
-#else
                     __builtin_amdgcn_raw_buffer_store_b128(ob, dY, off, 0, P8_STORE_AUX);
-#endif
                 }
             };
             if constexpr (!ZR) rows(std::integral_constant<int, 0>());
@@ -502,11 +479,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         mailbox[1] = (cap >= 3 && i1 >= 0) ? p8_fetch_item(a.sched, xcd, nlists, G, Gx, nit) : -1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-#if P8_RELAX
-    P8_VMCNT(0);                         // the whole prologue has landed: the relaxed counts of a tile's first phases assume that
-#else                                    // everything issued before the tile is complete, or older than the epilogue's stores
     P8_VMCNT(11);                        // units -1 and 0 have landed
-#endif
     P8_BARRIER();
     rdW(fwA, 7);
     P8_LGKM0();
@@ -534,7 +507,6 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         }                                                                                        \
         P8_VMCNT(WAITN);                                                                         \
         P8_BARRIER();                                                                            \
-        P8_LGKM_PHASE();                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         __builtin_amdgcn_s_setprio(1);                                                           \
         /* the barrier that hands the matrix pipe to the partner wave sits BEFORE this wave's last MFMA: the partner's first      */ \
@@ -549,11 +521,8 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
     } while (0)
 
 #define P8_PHASE(READ, TY, SLOT, DK, FX, FW, J0, T0) P8_PHASE_M(READ, TY, SLOT, DK, FX, FW, J0, T0, P8_MM, 10)
-    // the first 5 phases of an output tile: the previous tile's 16 output stores and this tile's bias load sit in the (single,
-    // in-order) VMEM queue between the units still in flight and the ones issued now.  The unit a phase needs is OLDER than all
-    // of them, so the count that keeps "5 younger units in flight" grows by 17: with vmcnt(10) the first phase of every tile
-    // would wait for the stores to be acknowledged (a 128 KiB burst per CU: 3-10k clocks) instead of running under them.
-#define P8_PHASE_T(READ, TY, SLOT, DK, FX, FW, J0, T0) P8_PHASE_M(READ, TY, SLOT, DK, FX, FW, J0, T0, P8_MM, 27)
+    // (Relaxed counts -- vmcnt(27) -- in a tile's first five phases, so that they do not wait for the previous tile's 16 output stores:
+    // measured neutral in rounds 2 and 3 -- the phases run at full speed, the epilogue stretches by as much -- and removed.)
     for (;;) {
         P8_STAMP(it);
         for (int kt = 0; kt < nk; kt += 2) {
@@ -581,9 +550,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
             // the clock stamps).  One extra barrier each re-aligns them: waves 0-3 take theirs before the epilogue (it pairs with
             // the barrier inside waves 4-7's last MFMA cluster), waves 4-7 after the tile switch (it pairs with the first barrier
             // of waves 0-3's next phase) -- both groups then do their epilogues between the same two barriers, side by side.
-#if P8_REALIGN
             if (!wr) P8_BARRIER();
-#endif
             // dynamic schedule: one lane asks for the item after the next one now -- the answer comes back under the epilogue -- and
             // leaves it in the mailbox slot of this tile's parity, which every wave reads at the NEXT tile switch (a whole tile and
             // dozens of barriers from now; the other slot is the one being read at this switch)
@@ -591,16 +558,10 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
             // slot is never read again would take an item out of the lists for good)
             int fetched = -1;
             if (dyn && tid == 0 && have_next && mailbox[(it + 1) & 1] >= 0) fetched = p8_fetch_item(a.sched, xcd, nlists, G, Gx, a.total * a.nsplit);
-#if !(P8_ABLATE & 1)
             epilogue();
-#endif
             if (dyn && tid == 0) mailbox[it & 1] = fetched;
             P8_STAMP(it);
-#if P8_REALIGN
             if (!have_next) { if (wr) P8_BARRIER(); break; }
-#else
-            if (!have_next) break;
-#endif
         }
         ++it;
         m0 = m1;
@@ -615,9 +576,7 @@ template <int ACT, bool ZR> __global__ __launch_bounds__(512) void gemm8p_kernel
         dXn = mk_desc(a.X, m1, a.M, a.ldx, k1, have_next);
         dWn = mk_desc(a.W, n1, a.N, a.ldw, k1, have_next);
         fetch_bias(n0, it);              // the next tile's bias values: consumed by its epilogue a whole tile from now
-#if P8_REALIGN
         if (wr) P8_BARRIER();
-#endif
     }
     P8_VMCNT(0);                         // no LDS-DMA may outlive the workgroup
     if (!wr) P8_BARRIER();               // balance the stagger barrier

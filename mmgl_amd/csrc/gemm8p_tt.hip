@@ -23,12 +23,6 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-#ifndef T8_ABLATE
-#define T8_ABLATE 0        // timing experiments only (1: every LDS-DMA reads K tile 0, 2: fragments read once, 3: no LDS-DMA, 4: no wait for the LDS-DMA, 5: ds_read_b128 in place of the two transpose reads); never set in a shipped build
-#endif
-#ifndef T8_ROLL
-#define T8_ROLL 1          // 1: fragments of the next phase are read inside the MFMA cluster (rolling reloads); 0: a read block ahead of every phase
-#endif
 constexpr int T8_UNIT = 16384;
 constexpr int T8_LDS = 8 * T8_UNIT;
 
@@ -59,9 +53,6 @@ __device__ __forceinline__ bf16x8 t8_frag(const char* unit, int blk, int ks, int
     const int i = lane & 15, g = lane >> 4;
     const int row = ks * 32 + 4 * g + (i >> 2);             // row + 16 has the same (row & 7)
     const char* p = unit + row * 256 + ((blk ^ (row & 7)) << 5) + (i & 3) * 8;
-#if T8_ABLATE == 5
-    return *(const bf16x8*)(unit + row * 256 + ((blk ^ (row & 7)) << 5) + (i & 1) * 16);      // one plain 16-byte read per fragment (wrong data, same bytes)
-#endif
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * 256));
     bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -228,56 +219,10 @@ __global__ __launch_bounds__(512) void gemm8p_tt_kernel(T8Args a) {
     T8_VMCNT(10);
     T8_BARRIER();
     rdA(faA, 7);
-#if T8_ROLL
     rdB(fb, 0);
-#endif
     T8_LGKM0();
     if (wr) T8_BARRIER();
 
-#if !T8_ROLL
-    // the read-block form (a block of transpose reads ahead of every phase's barrier), kept for comparison: same inline-asm reads
-#define T8_RDB(S) do { T8_FRAG(fb[0][0], fbase_b, fbase_b_hi, S, 0, 0); T8_FRAG(fb[0][1], fbase_b, fbase_b_hi, S, 1, 0); \
-                       T8_FRAG(fb[0][2], fbase_b, fbase_b_hi, S, 2, 0); T8_FRAG(fb[0][3], fbase_b, fbase_b_hi, S, 3, 0); \
-                       T8_FRAG(fb[1][0], fbase_b, fbase_b_hi, S, 0, 1); T8_FRAG(fb[1][1], fbase_b, fbase_b_hi, S, 1, 1); \
-                       T8_FRAG(fb[1][2], fbase_b, fbase_b_hi, S, 2, 1); T8_FRAG(fb[1][3], fbase_b, fbase_b_hi, S, 3, 1); } while (0)
-#define T8_RDA(F, S) do { T8_FRAG(F[0][0], fbase_a, fbase_a_hi, S, 0, 0); T8_FRAG(F[0][1], fbase_a, fbase_a_hi, S, 1, 0); \
-                          T8_FRAG(F[1][0], fbase_a, fbase_a_hi, S, 0, 1); T8_FRAG(F[1][1], fbase_a, fbase_a_hi, S, 1, 1); } while (0)
-#define T8_PHASE(READ, TY, SLOT, DK, FB, FA, J0, T0)                                             \
-    do {                                                                                         \
-        if (T8_ABLATE != 2 || kt == 0) { READ; }                                                 \
-        if (T8_ABLATE != 3) {                                                                    \
-            const int kk_ = kt + (DK);                                                           \
-            const bool nx_ = kk_ >= nk;                                                          \
-            const int ki_ = T8_ABLATE == 1 ? 0 : (nx_ ? kk_ - nk : kk_);                         \
-            if ((TY) & 1) stage((TY), (SLOT), nx_ ? dAn : dAc, ki_ * stepA);                     \
-            else stage((TY), (SLOT), nx_ ? dBn : dBc, ki_ * stepB);                              \
-        }                                                                                        \
-        if (T8_ABLATE != 4) T8_VMCNT(10);                                                        \
-        T8_BARRIER();                                                                            \
-        T8_LGKM0();                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        __builtin_amdgcn_s_setprio(1);                                                           \
-        T8_MM(FB, FA, J0, T0, 0, 15);                                                            \
-        T8_LGKM0();                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        T8_BARRIER();                                                                            \
-        T8_MM(FB, FA, J0, T0, 15, 16);                                                           \
-        __builtin_amdgcn_s_setprio(0);                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-    } while (0)
-
-    for (;;) {
-        for (int kt = 0; kt < nk; kt += 2) {
-            T8_PHASE(T8_RDB(0), 2, 6, 1, fb, faA, 0, 0);
-            T8_PHASE(T8_RDA(faB, 1), 3, 7, 2, fb, faB, 0, 2);
-            T8_PHASE(T8_RDB(2), 0, 0, 2, fb, faB, 4, 2);
-            T8_PHASE(T8_RDA(faB, 3), 1, 1, 2, fb, faA, 4, 0);
-            T8_PHASE(T8_RDB(4), 2, 2, 2, fb, faB, 0, 0);
-            T8_PHASE(T8_RDA(faA, 5), 3, 3, 3, fb, faA, 0, 2);
-            T8_PHASE(T8_RDB(6), 0, 4, 3, fb, faA, 4, 2);
-            T8_PHASE(T8_RDA(faA, 7), 1, 5, 3, fb, faB, 4, 0);
-        }
-#else
     // Rolling fragment reloads.  A fragment costs TWO transpose reads, a phase that refills the eight B fragments issues 16 of them,
     // and as a block in front of the MFMAs that does not fit beside the partner wave's 272 MFMA clocks (the NT kernel
     // with half the LDS instructions runs 40 % faster on the same flops).  So no phase reads ahead of its barrier any more: the
@@ -340,7 +285,6 @@ __global__ __launch_bounds__(512) void gemm8p_tt_kernel(T8Args a) {
             T8_PHASE2(0, 4, 3, fb, faA, 4, 2, T8_H7);      // Bb' x Ab'    | reads Aa'' -> faA
             T8_PHASE2(1, 5, 3, fb, faB, 4, 0, T8_H8);      // Bb' x Aa'    | reads Ba'' -> fb
         }
-#endif
         epilogue();
         if (!have_next) break;
         ++it;

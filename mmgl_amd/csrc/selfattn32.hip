@@ -37,9 +37,6 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef SA32_THR
 #define SA32_THR 8.0f             // deferred rescale threshold (log2 units)
 #endif
-#ifndef SA32_ABLATE
-#define SA32_ABLATE 0             // timing experiments only, results are wrong (1: K / V tiles fetched once, 2: no per-tile barrier, 4: no exp / max / sum)
-#endif
 #ifndef SA32_NS64
 #define SA32_NS64 2               // ring slots at head_dim 64 (3: two tiles in flight, 3 workgroups per CU; 2: one tile, 4 workgroups)
 #endif
@@ -54,9 +51,6 @@ typedef __attribute__((address_space(3))) void lds_void;
 #endif
 #ifndef SA32_TRACE
 #define SA32_TRACE 0              // timing experiments only: wall-clock stamps of every workgroup of the forward kernel (MMGL_SA32_TRACE = device pointer)
-#endif
-#ifndef SA32_VEARLY
-#define SA32_VEARLY 1             // V^T fragments requested before the softmax arithmetic (their latency hides under it)
 #endif
 
 template <int D> struct G32 {
@@ -238,7 +232,7 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
                     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[blk][jj][1]) : "v"(ad), "i"((32 * blk + 16 * jj + 8) * G::ROWB));
                 }
         };
-        if (SA32_VEARLY) vreads(0, va[0]);
+        vreads(0, va[0]);                                     // V^T fragments requested before the softmax arithmetic: their latency hides under it (+4 % otherwise)
 
         // ---- masks (wave-uniform branches: ordinary tiles run none of this)
         if (mixed) {
@@ -260,7 +254,6 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
                 }
             }
         }
-#if !(SA32_ABLATE & 4)
         // ---- online softmax (log2 domain), one query row per lane pair
         float tm = s[0][0];
 #pragma unroll
@@ -292,7 +285,6 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
                 ps[r & 3] += p;
             }
         lsum += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-#endif
         bf16x8 pf[NB][2];
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk)
@@ -303,7 +295,6 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
                 for (int e = 0; e < 8; ++e) t[e] = s[blk][8 * jj + e];
                 pf[blk][jj] = __builtin_convertvector(t, bf16x8);
             }
-        if (!SA32_VEARLY) vreads(0, va[0]);
 #pragma unroll
         for (int db = 0; db < G::NDB; ++db) {
             bf16x4 (&f)[NB][2][2] = va[db & 1];
@@ -349,7 +340,7 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
 #endif
     uint64_t vm = vbits[0];
     int slot = 0, islot = PD % G::NS;
-    for (int j = 0; j < ((SA32_ABLATE & 16) ? 0 : nkt); ++j) {
+    for (int j = 0; j < nkt; ++j) {
 #if SA32_TRACE
         if (j == 1) tr2 = wall_clock64();
 #endif
@@ -359,11 +350,11 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
         } else {
             SA32_VMCNT(0);
         }
-        if (!(SA32_ABLATE & 2)) SA32_BARRIER();
-        if (j + PD < nkt && !(SA32_ABLATE & 1) && !(EARLY && j == 0)) issue(j + PD, islot);
+        SA32_BARRIER();
+        if (j + PD < nkt && !(EARLY && j == 0)) issue(j + PD, islot);
         const uint64_t vnext = vbits[min(j + 1, nkt - 1)];
         const uint32_t vlo = __builtin_amdgcn_readfirstlane((uint32_t)vm), vhi = __builtin_amdgcn_readfirstlane((uint32_t)(vm >> 32));
-        if (j <= jlast && (vlo | vhi) != 0u && !(SA32_ABLATE & 8)) {
+        if (j <= jlast && (vlo | vhi) != 0u) {
             const bool mixed = (vlo & vhi) != 0xffffffffu;
             // (a one-block variant of the body for a diagonal tile whose second 32 keys lie above the whole wave would save 5 % of
             // the block steps at T = 640; as a second inlined body it costs 42 VGPRs and 48 accumulator copies per tile)

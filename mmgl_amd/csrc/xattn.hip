@@ -84,7 +84,6 @@ __global__ __launch_bounds__(256, MMGL_XATTN_MINWAVES) void xattn_fwd_kernel(con
         for (int dc = 0; dc < C::NDC; ++dc)
             qn[qt][dc] = buf_load8<T>(rq, row_off<T, C>((t0 < wg_end) ? t0 + qt * 16 + x : T_, row_bytes, dc * 32 + g * 8));
 
-#if !(MMGL_XATTN_ABLATE & 2)
     {   // K, V and the key mask in ONE memory round trip (ImageStage); the mask byte is only loaded here, its select sits at the store
         const uint32_t slab_kv = (uint32_t)(((size_t)(S - 1) * HD + D) * sizeof(T));
         const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * S * HD + h * D, slab_kv);
@@ -100,7 +99,6 @@ __global__ __launch_bounds__(256, MMGL_XATTN_MINWAVES) void xattn_fwd_kernel(con
         if ((int)threadIdx.x < C::SPAD) vld[threadIdx.x] = (vi < S) ? vraw : (uint8_t)0;
     }
     __syncthreads();
-#endif
 
     uint32_t vlo, vhi, elo, ehi;
     lane_key_bits<C>(vld, g, S, vlo, vhi, elo, ehi);
@@ -143,19 +141,6 @@ __global__ __launch_bounds__(256, MMGL_XATTN_MINWAVES) void xattn_fwd_kernel(con
             for (int dc = 0; dc < C::NDC; ++dc)
                 qn[qt][dc] = buf_load8<T>(rq, row_off<T, C>((tn < wg_end) ? tn + qt * 16 + x : T_, row_bytes, dc * 32 + g * 8));
 
-#if (MMGL_XATTN_ABLATE & 1)
-        // timing ablation only: no MFMA / softmax, O := first channels of Q (streaming ceiling of this access pattern)
-#pragma unroll
-        for (int qt = 0; qt < C::QT; ++qt) {
-            lst[qt] = 0.f;
-#pragma unroll
-            for (int db = 0; db < C::NDB; ++db) {
-                f32x4 t4 = {(float)qf[qt][db % C::NDC][0], (float)qf[qt][db % C::NDC][1], (float)qf[qt][db % C::NDC][2], (float)qf[qt][db % C::NDC][3 + db / C::NDC]};
-                ost[qt][db] = cvt4<T>(t4);
-            }
-        }
-        continue;
-#endif
         f32x4 sacc[C::QT][C::NSB];
 #pragma unroll
         for (int sb = 0; sb < C::NSB; ++sb) {
