@@ -45,7 +45,7 @@ CONFIGS = {
     # configs[3]: LoRA r=16 on q_proj / v_proj of OPT-1.3B, neighbors concatenated into the sequence (T = 640 + 64), lm_head trainable
     "opt-1.3b-lora": dict(kind="lora", lm=dict(vocab_size=50272, hidden_size=2048, num_attention_heads=32, ffn_dim=8192, num_hidden_layers=24,
                                                max_position_embeddings=2048, word_embed_proj_dim=2048), nt=11, ni=5, wise=6,
-                          model_name="facebook/opt-1.3b", batch=32, lin=512, lout=128, vocab=50272, lora_r=16,
+                          model_name="facebook/opt-1.3b", batch=58, lin=512, lout=128, vocab=50272, lora_r=16,
                           metric="train samples/sec (OPT-1.3B LoRA r=16, 16 neighbors, self-attention fusion)"),
     # configs[4]: Llama-2-7B dims, 32 neighbors (22 text + 10 image) x 4 tokens, max_input_length 2048 -> T = 2176, S = 128
     "llama-2-7b": dict(kind="llama", lm=dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,

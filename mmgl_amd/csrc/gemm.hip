@@ -670,6 +670,15 @@ int launch_gemm_tx(bool tb, const bf16* Aop, int lda, const bf16* Bop, int ldb, 
                    int K, float scale, int accumulate, hipStream_t st, float* part = nullptr) {
     MMGL_CHECK_ARG(RA > 0 && RB > 0 && K > 0, "gemm_tx: bad sizes");
     if (RA % 8 || (tb ? RB % 8 : K % 8)) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "gemm_tx: feature dims must be multiples of 8");
+    if (tb && !ymask && K >= 1024 && ((long long)K * lda * 2 >= 0xffffffffLL || (long long)K * ldb * 2 >= 0xffffffffLL)) {
+        // a k-major operand of 4 GiB or more (the trainable lm_head's weight gradient at config 4 from B = 64 on: dlogits is
+        // [45056, 50272] bf16 = 4.5 GB) does not fit one buffer descriptor: contract the two halves of the rows one after the other,
+        // the second accumulating into the first one's output
+        const int K1 = (K / 2 + 255) / 256 * 256;
+        int rc = launch_gemm_tx(tb, Aop, lda, Bop, ldb, nullptr, Out, RA, RB, K1, scale, accumulate, st, part);
+        if (rc) return rc;
+        return launch_gemm_tx(tb, Aop + (size_t)K1 * lda, lda, Bop + (size_t)K1 * ldb, ldb, nullptr, Out, RA, RB, K - K1, scale, 1, st, part);
+    }
     if (tb && !ymask && tune_gemm_8p()) {
         // both operands k-major and enough (tile, K split) work items: the ping-pong weight-gradient kernel (gemm8p_tt.hip)
         const int s8 = gemm8p_tt_splits(RA, RB, K);

@@ -203,3 +203,24 @@ def test_config4_lora_attention_layer_fused_qkv_node_vs_separate_projections(mon
     assert_close(dx1, dx2, 3e-2, "dx")
     for n_ in g1:
         assert_close(g1[n_], g2[n_], 3e-2, n_)
+
+
+def test_weight_gradient_with_an_operand_above_4_gib():
+    """Config 4 trains lm_head (peft modules_to_save, reference model/modelling_self_attention.py:80-87): from B = 64 on its weight
+    gradient contracts dlogits [45056, 50272] bf16 = 4.5 GB, more than one buffer descriptor (4 GiB) covers.  The contraction is
+    cut into two row halves, the second accumulating (csrc/gemm.hip: launch_gemm_tx); before round 4 this raised."""
+    from mmgl_amd import ops
+    M, N, K = 45056, 50272, 2048
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = (torch.randn(M, K, device="cuda", generator=g) * 0.5).bfloat16()
+    W = (torch.randn(N, K, device="cuda", generator=g) * 0.02).bfloat16().requires_grad_()
+    y = ops.linear(x, W, None)
+    dy = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    assert dy.numel() * 2 > 2 ** 32
+    y.backward(dy)
+    ref = torch.zeros(N, K, device="cuda")
+    for r0 in range(0, M, 5632):                               # fp32 reference in row chunks (dy in fp32 would be 9 GB at once)
+        ref += dy[r0:r0 + 5632].float().t() @ x[r0:r0 + 5632].float()
+    err = float((W.grad.float() - ref).abs().max() / ref.abs().max())
+    print(f"dW of a 4.5 GB dy: rel err {err:.2e}")
+    assert err < 1e-2, err
