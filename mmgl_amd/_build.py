@@ -24,6 +24,23 @@ CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-r
           "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
+# per-file flag changes: the four-wave GEMM keeps its 256 accumulators in the AGPR half of the register file (the VGPR form would
+# have to fit accumulators AND operands into 256 registers)
+DROP_FLAGS = {"gemm4w.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
+def _cflags(src):
+    drop = DROP_FLAGS.get(os.path.basename(src), [])
+    out, i = [], 0
+    while i < len(CFLAGS):
+        if drop and CFLAGS[i:i + len(drop)] == drop:
+            i += len(drop)
+            continue
+        out.append(CFLAGS[i])
+        i += 1
+    return out
+
+
 def _newer(src, dst, deps):
     if not os.path.exists(dst):
         return True
@@ -44,7 +61,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + CFLAGS + extra + ["-c", s, "-o", o]
+        cmd = [HIPCC] + _cflags(s) + extra + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}\n{r.stderr}")

@@ -13,6 +13,7 @@
 #include <string.h>
 #include <rccl/rccl.h>
 #include <mutex>
+#include <string>
 
 namespace {
 
@@ -25,7 +26,9 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;      // optional: only to validate a broadcast root
     bool ok = false;
+    std::string why;           // dlerror() text captured once, at dlopen time (dlerror() clears itself when read)
 };
 
 Rccl& rccl() {
@@ -41,7 +44,11 @@ Rccl& rccl() {
                 r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
                 if (r.h) break;
             }
-        if (!r.h) return;
+        if (!r.h) {
+            const char* e = dlerror();
+            r.why = e ? e : "dlopen failed";
+            return;
+        }
 #define RCCL_SYM(field, sym) r.field = (decltype(r.field))dlsym(r.h, sym)
         RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
         RCCL_SYM(CommInitRank, "ncclCommInitRank");
@@ -50,8 +57,10 @@ Rccl& rccl() {
         RCCL_SYM(AllGather, "ncclAllGather");
         RCCL_SYM(Broadcast, "ncclBroadcast");
         RCCL_SYM(GetErrorString, "ncclGetErrorString");
+        RCCL_SYM(CommCount, "ncclCommCount");
 #undef RCCL_SYM
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.AllGather && r.Broadcast && r.GetErrorString;
+        if (!r.ok) r.why = "symbols missing";
     });
     return r;
 }
@@ -67,7 +76,7 @@ int comm_dtype(const char* who, int dtype, ncclDataType_t* out) {
 
 #define RCCL_REQUIRE(who)                                                                                        \
     Rccl& R = rccl();                                                                                            \
-    if (!R.ok) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "%s: librccl.so could not be loaded (%s)", who, dlerror() ? dlerror() : "symbols missing")
+    if (!R.ok) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "%s: librccl.so could not be loaded (%s)", who, R.why.c_str())
 #define RCCL_CHECK(who, expr)                                                                                    \
     do {                                                                                                         \
         ncclResult_t rc_ = (expr);                                                                               \
@@ -122,6 +131,11 @@ extern "C" int mmgl_broadcast(void* comm, void* buf, size_t count, int dtype, in
     RCCL_REQUIRE("mmgl_broadcast");
     ncclDataType_t dt;
     if (int rc = comm_dtype("mmgl_broadcast", dtype, &dt)) return rc;
+    if (R.CommCount) {
+        int world = 0;
+        RCCL_CHECK("mmgl_broadcast", R.CommCount((ncclComm_t)comm, &world));
+        MMGL_CHECK_ARG(root < world, "mmgl_broadcast: root %d of a %d-rank communicator", root, world);
+    }
     if (!count) return MMGL_OK;
     RCCL_CHECK("mmgl_broadcast", R.Broadcast(buf, buf, count, dt, root, (ncclComm_t)comm, (hipStream_t)stream));
     return MMGL_OK;

@@ -709,7 +709,8 @@ static std::atomic<unsigned*> g_tile_counter[64];
 static std::atomic<int> g_tile_counters_set{0};
 // The one counter block of a device serves ONE stream: two launches in flight on different streams would hand out each other's
 // tiles.  The first launch after mmgl_gemm_set_tile_counter binds the device's counters to its stream; a launch on any other stream
-// while they are set is refused (MMGL_ERR_INVALID) instead of corrupting both schedules.
+// while they are set runs on the STATIC schedule (it never touches the counters: eval / prefetch / encoder work on a side stream
+// stays legal, it just does not yield tiles to a co-resident collective).  MMGL_GEMM_STRICT_STREAM=1 turns that case into an error.
 static hipStream_t const P8_STREAM_UNBOUND = (hipStream_t)(intptr_t)-1;
 static std::atomic<hipStream_t> g_tile_stream[64];
 static unsigned* p8_tile_counter() {
@@ -772,9 +773,18 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
     a.trace = nullptr;
     a.trace_wg = 0;
     a.tile0 = 0;
-    if (!p8_tile_counter_for(st, &a.sched))
-        MMGL_FAIL(MMGL_ERR_INVALID, "gemm8p: the dynamic tile schedule of this device is bound to another stream (one stream per device "
-                                    "while mmgl_gemm_set_tile_counter is in effect)");
+    if (!p8_tile_counter_for(st, &a.sched)) {
+        static const bool strict = getenv("MMGL_GEMM_STRICT_STREAM") && atoi(getenv("MMGL_GEMM_STRICT_STREAM"));
+        if (strict)
+            MMGL_FAIL(MMGL_ERR_INVALID, "gemm8p: the dynamic tile schedule of this device is bound to another stream (one stream per device "
+                                        "while mmgl_gemm_set_tile_counter is in effect)");
+        a.sched = nullptr;                               // static schedule for this launch
+    }
+    {
+        static const int use4w = getenv("MMGL_GEMM_4W") ? atoi(getenv("MMGL_GEMM_4W")) : 0;
+        if (use4w && act == 0 && !resid && !zmask && !bits_out && !bits_in && !nsplit && !a.sched && gemm4w_supported(M, N, K, ldx, ldw, ldy))
+            return launch_gemm4w(X, ldx, W, ldw, Y, ldy, bias, M, N, K, scale, st);
+    }
     if (direct > 0) {
         a.total = direct;
         const int grid = direct < n_cu ? direct : n_cu;

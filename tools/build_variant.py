@@ -18,7 +18,7 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     base = os.path.basename(src)[:-4]
     obj = os.path.join(out_dir, f"{base}_{name}.o")
-    subprocess.run([_build.HIPCC] + _build.CFLAGS + flags + ["-c", os.path.join(_build.CSRC, os.path.basename(src)), "-o", obj], check=True)
+    subprocess.run([_build.HIPCC] + _build._cflags(src) + flags + ["-c", os.path.join(_build.CSRC, os.path.basename(src)), "-o", obj], check=True)
     objs = [obj if os.path.basename(o)[:-2] == base else o
             for o in (os.path.join(_build.OBJ, f) for f in sorted(os.listdir(_build.OBJ)) if f.endswith(".o"))]
     lib = os.path.join(out_dir, f"lib_{name}.so")
