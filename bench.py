@@ -40,12 +40,12 @@ CONFIGS = {
                      metric="train samples/sec (OPT-1.3B flamingo, 16 neighbors)"),
     "opt-125m": dict(kind="flamingo", lm=dict(vocab_size=50272, hidden_size=768, num_attention_heads=12, ffn_dim=3072, num_hidden_layers=12,
                                               max_position_embeddings=2048, word_embed_proj_dim=768), nt=2, ni=2, wise=3,
-                     model_name="facebook/mpt-125m", batch=102, lin=512, lout=128, vocab=50272,
+                     model_name="facebook/mpt-125m", batch=64, lin=512, lout=128, vocab=50272,
                      metric="train samples/sec (OPT-125m flamingo, 4 neighbors)"),
     # configs[3]: LoRA r=16 on q_proj / v_proj of OPT-1.3B, neighbors concatenated into the sequence (T = 640 + 64), lm_head trainable
     "opt-1.3b-lora": dict(kind="lora", lm=dict(vocab_size=50272, hidden_size=2048, num_attention_heads=32, ffn_dim=8192, num_hidden_layers=24,
                                                max_position_embeddings=2048, word_embed_proj_dim=2048), nt=11, ni=5, wise=6,
-                          model_name="facebook/opt-1.3b", batch=58, lin=512, lout=128, vocab=50272, lora_r=16,
+                          model_name="facebook/opt-1.3b", batch=64, lin=512, lout=128, vocab=50272, lora_r=16,
                           metric="train samples/sec (OPT-1.3B LoRA r=16, 16 neighbors, self-attention fusion)"),
     # configs[4]: Llama-2-7B dims, 32 neighbors (22 text + 10 image) x 4 tokens, max_input_length 2048 -> T = 2176, S = 128
     "llama-2-7b": dict(kind="llama", lm=dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
@@ -284,7 +284,7 @@ def cpu_protocol(cores):
     return out
 
 
-def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1, repeats=3, protocol=True):
+def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1, repeats=3, protocol=True, all_threads_too=False):
     """The CPU oracle on the host cores, same bench run (kind "port"; the reference's Python does not travel).  `value`: the bench's own
     workload -- config 3's train step (frozen encoders fwd, LM fwd + bwd w.r.t. the trainable set) on a bounded sample: one warm-up,
     then the median of `repeats` runs of `n_samples` sample(s) (6 s each: the section-3 count of 2 + 5 would be 40 s).  `section3`:
@@ -294,6 +294,15 @@ def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1, repeats=3, protocol=Tru
     once = _cpu_step(model, cfg, lm_cfg, batch, n_samples)
     loss = once()                                       # warm-up (thread pool, allocator)
     dt, runs = _median_time(once, 0, repeats)
+    all_threads = None
+    if all_threads_too and os.cpu_count() and os.cpu_count() != cores:
+        # BASELINE.md section 3 says os.cpu_count() threads: one run of the same sample with every logical CPU, beside the figure
+        # above (the reason `cores` is 32: torch's fp32 GEMM does not scale past that on this host class).  Opt-in (--cpu-all-threads):
+        # it takes minutes on a 256-thread host, the default run has to finish in a few; the recorded figure is under profiles/.
+        torch.set_num_threads(os.cpu_count())
+        dt_all, _ = _median_time(once, 0, 1)
+        all_threads = dict(cores=os.cpu_count(), value=n_samples / dt_all, seconds=round(dt_all, 2))
+        torch.set_num_threads(cores)
     model.text_model.to(batch["input_ids"].device)
     model.visual_model.to(batch["input_ids"].device)
     out = dict(value=n_samples / dt, unit="samples/s", cores=cores, cpu_count=os.cpu_count(), cpu_model=_cpu_model(), kind="port",
@@ -301,6 +310,8 @@ def cpu_baseline(model, cfg, lm_cfg, batch, n_samples=1, repeats=3, protocol=Tru
                sample=f"median of {repeats} runs (after 1 warm-up) of {n_samples} sample(s) of the same synthetic batch: frozen encoders fwd + LM "
                       f"fwd + bwd (no optimizer step), fp32 torch oracle (oracle/), {cores} threads of {os.cpu_count()} logical CPUs "
                       f"(torch's fp32 GEMM collapses beyond 32 threads on this host class)", loss=loss)
+    if all_threads is not None:
+        out["all_threads"] = all_threads
     if protocol:
         out["section3"] = cpu_protocol(cores)
     return out
@@ -311,7 +322,7 @@ def pmc_traffic(B, lm_cfg, cfg, dtype):
     separate passes, gfx950 x2 fetch correction applied: profiles/r<round>_pmc_xattn_*.json) when it was taken at this exact
     shape, and the file it came from; (None, None) otherwise -- PMC counters cannot be read from inside this process, so `traffic` is
     a committed measurement of the same kernel at the same shape, NOT a counter of this run (`traffic_source` says which file)."""
-    for rnd in ("r4", "r3", "r2", "r1"):                     # the latest round's collection first
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):                     # the latest round's collection first
         rel = os.path.join("profiles", f"{rnd}_pmc_xattn_B{B}_{dtype}.json")
         try:
             with open(os.path.join(ROOT, rel)) as f:
@@ -336,9 +347,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=1)
+    ap.add_argument("--cpu-all-threads", action="store_true", help="cpu_baseline: also time ONE run of the same sample with os.cpu_count() threads "
+                    "(`all_threads`; minutes on a 256-thread host)")
     ap.add_argument("--force-exchange", action="store_true", help="--gpus 1 only: create a world_size-1 RCCL ('nccl') process group on the GPU and run "
                     "the data-parallel engine with its gradient exchange forced on (hook-launched async all-reduces, work.wait(), dynamic GEMM "
                     "tile schedule), reporting the `exchange` block: the device-side N>1 path on a 1-GPU box")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the `batch_sweep` block (the same step at per-GPU batches 4 / 16 / 32 / 64 up "
+                    "to the run's own batch, outside the timed region)")
     ap.add_argument("--ref-batch", type=int, default=4, help="also report the step at the reference's default per-device batch (Arguments default 4, run_generation.py:124-126); 0 = skip")
     args = ap.parse_args()
 
@@ -479,28 +494,39 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    # ---- the same step at the reference's own default batch (launch-bound regime: GEMM M = 4 * 640), outside the timed region
-    ref_line = None
-    if args.ref_batch and args.ref_batch < args.batch:
+    # ---- the same step at other per-GPU batches, outside the timed region: the reference's own default (launch-bound regime: GEMM
+    # M = 4 * 640) as `at_reference_batch`, and {4, 16, 32, 64} below the run's batch as `batch_sweep` (round 4 picked bench batches
+    # that land on whole rounds of 256x256 GEMM tiles; the default is a plain 64 again and the dependence is on the record)
+    def at_batch(bsz, seed, warm, n):
+        nonlocal batch
         keep = batch
-        batch, _ = synthetic_batch(args.ref_batch, cfg, seed=4321 + rank, device=device)
-        for _ in range(3):
+        batch, _ = synthetic_batch(bsz, cfg, seed=seed + rank, device=device)
+        for _ in range(warm):
             step()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        n_ref = 10
-        for _ in range(n_ref):
+        for _ in range(n):
             step()
         torch.cuda.synchronize()
         t1 = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(t1, op=dist.ReduceOp.MAX)
         t1 = float(t1.item())
-        ref_line = {"per_gpu_batch": args.ref_batch, "value": round(world * args.ref_batch * n_ref / t1, 3), "unit": "samples/s",
-                    "ms_per_step": round(1e3 * t1 / n_ref, 3), "steps": n_ref}
         batch = keep
+        return {"per_gpu_batch": bsz, "value": round(world * bsz * n / t1, 3), "unit": "samples/s", "ms_per_step": round(1e3 * t1 / n, 3), "steps": n}
+
+    ref_line = None
+    if args.ref_batch and args.ref_batch < args.batch:
+        ref_line = at_batch(args.ref_batch, 4321, 3, 10)
+    sweep = None
+    if not args.no_batch_sweep:
+        sweep = {}
+        for bsz in (4, 16, 32, 64):
+            if bsz < args.batch:
+                sweep[str(bsz)] = ref_line["value"] if (ref_line and bsz == args.ref_batch) else at_batch(bsz, 4321, 2, 6)["value"]
+        sweep[str(args.batch)] = round(world * args.batch * args.steps / dt, 3)
 
     # ---- gradient-exchange report (outside the timed region; every rank runs the same collectives)
     exchange = None
@@ -608,10 +634,12 @@ def main():
             line["hip_path_ms_per_step"] = round(sum(s["ms_total"] for s in ks.values()) / table_steps, 2)
         if ref_line is not None:
             line["at_reference_batch"] = ref_line
+        if sweep is not None:
+            line["batch_sweep"] = {"unit": "samples/s (whole job) by per-GPU batch", **sweep}
         if exchange is not None:
             line["exchange"] = exchange
         if world == 1 and not args.no_cpu_baseline and cfg["kind"] == "flamingo":
-            line["cpu_baseline"] = cpu_baseline(model, cfg, lm_cfg, batch, args.cpu_samples)
+            line["cpu_baseline"] = cpu_baseline(model, cfg, lm_cfg, batch, args.cpu_samples, all_threads_too=args.cpu_all_threads)
     else:
         line = None
     if comm:

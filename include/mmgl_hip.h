@@ -22,8 +22,9 @@
  *     RuntimeError.
  *   - re-entrant.  Global state: the last-error string (thread-local), and ONE opt-in per-device setting, the dynamic tile
  *     schedule of the persistent GEMM (mmgl_gemm_set_tile_counter below): while it is set, that device's persistent-GEMM launches
- *     are bound to one stream (the first one that launches after the call) and a launch on another stream returns
- *     MMGL_ERR_INVALID.  With the default static schedule nothing is shared between calls.
+ *     COUNTERS are bound to one stream (the first one that launches after the call); a launch on another stream runs on the static
+ *     schedule (MMGL_GEMM_STRICT_STREAM=1: returns MMGL_ERR_INVALID instead).  With the default static schedule nothing is shared
+ *     between calls.
  */
 #ifndef MMGL_HIP_H
 #define MMGL_HIP_H
@@ -54,8 +55,8 @@ int mmgl_version(void);
  *   lse       [B,H,T] fp32 log-sum-exp of the masked scores (saved for backward)
  * A sample with no valid key yields the uniform distribution over its S keys (the reference's
  * finfo.min clamp, :226-228), never NaN.  D in {16,32,64,128}; S <= 256.
- * No attention dropout (:256): OPT's attention_dropout is 0.0, where it is the identity; the host mirror raises ValueError for
- * a config that asks for it instead of carrying inert p / seed / offset arguments here.
+ * No attention dropout here (:256): OPT's attention_dropout is 0.0, where it is the identity; a config that asks for it (or for a
+ * head mask / output_attentions) is routed to mmgl_attn_general_* below by the host mirror.
  */
 int mmgl_xattn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid,
                    void* out, float* lse, int B, int H, int T, int S, int D, int dtype, void* stream);
@@ -103,6 +104,32 @@ int mmgl_selfattn_prefix_fwd(const void* q, const void* k, const void* v, const 
 int mmgl_selfattn_prefix_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse,
                              const uint8_t* key_valid, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
                              int B, int H, int T, int P, int D, int ld_q, int ld_kv, int ld_dq, int ld_dkv, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * General attention core: the options of MPTAttention.forward the fused kernels above leave out -- attention-probability dropout,
+ * layer_head_mask, output_attentions -- for both call sites of the class (causal = 0: the gated cross-attention layers, key mask only;
+ * causal = 1: the decoder's self-attention, (s <= t) AND key_valid, S == T).
+ * replaces: model/modelling_cross_attention.py:206-271 incl. :237-244 (layer_head_mask scales the probabilities of a head),
+ *           :246-254 (attn_weights_reshaped: the head-masked probabilities, returned BEFORE dropout), :256 (nn.functional.dropout on
+ *           the probabilities); model/modelling_self_attention.py reaches the same class through the OPT decoder.
+ *   q [B,T,H*D] already scaled; k, v [B,S,H*D]; key_valid [B,S] uint8; head_mask [H] fp32 or NULL
+ *   out [B,T,H*D]; probs [B,H,T,S] (dtype of q) or NULL; lse [B,H,T] fp32 (+inf marks a query row without any allowed key: uniform
+ *   over all S keys, as the reference's finfo.min clamp gives)
+ *   p_drop in [0, 1): probability of dropping a probability; the keep mask is the counter hash of (seed, ((b H + h) T + t) S + s)
+ *   every dropout of this library uses, regenerated by the backward from the same (p_drop, seed) -- nothing is stored.
+ * Written for exactness, not speed (fp32 VALU arithmetic, two passes over the keys): these options are inert on every BASELINE config
+ * (attention_dropout = 0, no head masks); every other call stays on mmgl_xattn_* / mmgl_selfattn_*.  D <= 128, any S.
+ * mmgl_attn_dropout_mask writes the keep mask as bytes [B,H,T,S] (1 = kept): a test / debug entry point (the parity tests hand it to
+ * the oracle so both sides drop the same probabilities).
+ */
+int mmgl_attn_general_fwd(const void* q, const void* k, const void* v, const uint8_t* key_valid, const float* head_mask, void* out,
+                          void* probs, float* lse, int B, int H, int T, int S, int D, int causal, float p_drop,
+                          uint64_t seed, int dtype, void* stream);
+size_t mmgl_attn_general_bwd_workspace(int B, int H, int T);
+int mmgl_attn_general_bwd(const void* dout, const void* q, const void* k, const void* v, const float* lse, const uint8_t* key_valid,
+                          const float* head_mask, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes, int B, int H,
+                          int T, int S, int D, int causal, float p_drop, uint64_t seed, int dtype, void* stream);
+int mmgl_attn_dropout_mask(uint8_t* mask, int B, int H, int T, int S, float p_drop, uint64_t seed, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (affine, eps inside the sqrt) over the last dim.

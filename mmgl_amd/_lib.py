@@ -11,7 +11,7 @@ import torch  # imported first on purpose: the .so must bind to the HIP runtime 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMGL_LIB_PATH") or os.path.join(_HERE, "libmmgl_hip.so")     # override: timing experiments with ablated builds
 
-ABI_VERSION = 103         # = mmgl_version() of the library this binding was written against (csrc/lib.hip)
+ABI_VERSION = 104         # = mmgl_version() of the library this binding was written against (csrc/lib.hip)
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
 _ERR_INVALID, _ERR_UNSUPPORTED, _ERR_HIP = 1, 2, 3
@@ -32,6 +32,10 @@ SIGNATURES = {
     "mmgl_selfattn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, I, P]),
     "mmgl_selfattn_prefix_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "mmgl_selfattn_prefix_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, I, I, I, I, P]),
+    "mmgl_attn_general_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, U, I, P]),
+    "mmgl_attn_general_bwd_workspace": (Z, [I, I, I]),
+    "mmgl_attn_general_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, F, U, I, P]),
+    "mmgl_attn_dropout_mask": (I, [P, I, I, I, I, F, U, P]),
     "mmgl_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, I, P]),
     "mmgl_norm_bwd_workspace": (Z, [I, I]),
     "mmgl_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, I, P]),

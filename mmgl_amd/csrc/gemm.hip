@@ -196,7 +196,13 @@ inline constexpr int tune_gemm_mid() { return 1; }       // 1: gemm_mid_kernel t
 inline int gemm8p_row_split(int M, int N, int K, int ldx, int ldw, int ldy) {
     const int G = gemm8p_num_cu(), tm = cdiv(M, 256), tn = cdiv(N, 256);
     const int rounds = tm * tn / G, rem = tm * tn % G;
-    if (rounds < 1 || rounds > 3 || rem == 0 || rem > G / 4 || (rounds * G) % tn) return 0;
+    // round 5: also ANY number of whole rounds plus a remainder of a third to a half of a round (config 4 at B = 64: [45056, 2048]
+    // = 1408 tiles = 5.5 rounds): too big for the K-split remainder plan (gemm8p_plan: at least 3 splits), and as 128x128 tiles it is at
+    // most one round of the few-tile kernel's 512 slots (~0.73 of a persistent round instead of a whole one).  MMGL_GEMM_ROWSPLIT_BAND=0: off.
+    static const bool band = !(getenv("MMGL_GEMM_ROWSPLIT_BAND") && atoi(getenv("MMGL_GEMM_ROWSPLIT_BAND")) == 0);
+    const bool small_tail = rounds >= 1 && rounds <= 3 && rem > 0 && rem <= G / 4;
+    const bool half_tail = band && rounds >= 1 && rem > G / 3 && rem <= G / 2;
+    if (!(small_tail || half_tail) || (rounds * G) % tn) return 0;
     const int m1 = rounds * G / tn * 256;
     return (m1 > 0 && m1 < M && gemm_mid_supported(M - m1, N, K, ldx, ldw, ldy)) ? m1 : 0;
 }
@@ -674,10 +680,15 @@ int launch_gemm_tx(bool tb, const bf16* Aop, int lda, const bf16* Bop, int ldb, 
         // a k-major operand of 4 GiB or more (the trainable lm_head's weight gradient at config 4 from B = 64 on: dlogits is
         // [45056, 50272] bf16 = 4.5 GB) does not fit one buffer descriptor: contract the two halves of the rows one after the other,
         // the second accumulating into the first one's output
+        // (the caller sized `part` for the split count of the FULL contraction: a half whose own split count would need more
+        // fp32 partial tiles than that runs without scratch -- unsplit, or on the 128x128 kernel)
         const int K1 = (K / 2 + 255) / 256 * 256;
-        int rc = launch_gemm_tx(tb, Aop, lda, Bop, ldb, nullptr, Out, RA, RB, K1, scale, accumulate, st, part);
+        const size_t have = wgrad_partial_bytes(RA, RB, K);
+        float* p1 = wgrad_partial_bytes(RA, RB, K1) <= have ? part : nullptr;
+        float* p2 = wgrad_partial_bytes(RA, RB, K - K1) <= have ? part : nullptr;
+        int rc = launch_gemm_tx(tb, Aop, lda, Bop, ldb, nullptr, Out, RA, RB, K1, scale, accumulate, st, p1);
         if (rc) return rc;
-        return launch_gemm_tx(tb, Aop + (size_t)K1 * lda, lda, Bop + (size_t)K1 * ldb, ldb, nullptr, Out, RA, RB, K - K1, scale, 1, st, part);
+        return launch_gemm_tx(tb, Aop + (size_t)K1 * lda, lda, Bop + (size_t)K1 * ldb, ldb, nullptr, Out, RA, RB, K - K1, scale, 1, st, p2);
     }
     if (tb && !ymask && tune_gemm_8p()) {
         // both operands k-major and enough (tile, K split) work items: the ping-pong weight-gradient kernel (gemm8p_tt.hip)

@@ -16,4 +16,4 @@ extern "C" const char* mmgl_last_error(void) { return g_err; }
 // stale build would otherwise load and run with misaligned arguments).  101: mmgl_xattn_fwd lost p_drop / seed / offset.
 // 102: round 4 (tile counters bound to one stream; entry points added / removed with the kernel families).
 // 103: mmgl_comm_* / mmgl_allreduce_sum / mmgl_allgather / mmgl_broadcast.
-extern "C" int mmgl_version(void) { return 103; }
+extern "C" int mmgl_version(void) { return 104; }

@@ -22,6 +22,7 @@
 // Both are "fragment linear": a fragment read is one conflict-free ds_read_b128 per lane.
 // fp32 activations skip the t image (LDS budget) and gather it from the row image with scalar reads.
 #include "attn_common.h"
+#include <atomic>
 
 namespace {
 
@@ -1350,11 +1351,32 @@ void fwd_geometry(int B, int H, int T, int tile_rows, int& rows_per_wg, int& nch
     nchunk = (T + rows - 1) / rows;
 }
 
+// hipFuncSetAttribute once per (kernel, device) and LDS size it has not been raised to yet: at the reference's batch the step is
+// launch-bound and this call sat in front of every cross-attention launch above 48 KiB
 template <typename K> int set_lds(K kern, size_t bytes) {
     if (bytes > 160 * 1024) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "xattn: S*D needs %zu B of LDS (> 160 KiB)", bytes);
-    if (bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (bytes <= 48 * 1024) return MMGL_OK;
+    struct Slot { std::atomic<const void*> fn{nullptr}; std::atomic<int> dev{-1}; std::atomic<size_t> bytes{0}; };
+    static Slot slots[128];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const void* fn = (const void*)kern;
+    Slot* mine = nullptr;
+    for (Slot& sl : slots) {
+        const void* f = sl.fn.load(std::memory_order_acquire);
+        if (f == fn && sl.dev.load(std::memory_order_relaxed) == dev) { mine = &sl; break; }
+        if (!f) {
+            const void* expect = nullptr;
+            if (sl.fn.compare_exchange_strong(expect, fn, std::memory_order_acq_rel)) { sl.dev.store(dev, std::memory_order_relaxed); mine = &sl; break; }
+            if (expect == fn && sl.dev.load(std::memory_order_relaxed) == dev) { mine = &sl; break; }
+        }
+    }
+    if (mine && mine->bytes.load(std::memory_order_acquire) >= bytes) return MMGL_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (mine) {
+        size_t cur = mine->bytes.load(std::memory_order_relaxed);
+        while (cur < bytes && !mine->bytes.compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
     }
     return MMGL_OK;
 }

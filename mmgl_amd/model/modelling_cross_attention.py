@@ -151,10 +151,9 @@ class MPTAttention(nn.Module):
     def _forward_cross(self, hidden_states, neighbor_embeds, neighbor_attention_mask, layer_head_mask, output_attentions):
         if neighbor_embeds is None:
             raise ValueError("cross-attention layer called without neighbor_embeds")
-        if layer_head_mask is not None or output_attentions:
-            raise ValueError("layer_head_mask / output_attentions are not available on the fused cross-attention kernel")
-        if self.training and self.dropout > 0:
-            raise ValueError("attention_dropout > 0 is not implemented in the fused cross-attention kernel (OPT uses 0.0)")
+        # layer_head_mask / output_attentions / attention-probability dropout (reference :237-256): the general HIP core
+        # (ops.attn_general, exact and unfused); everything else -- every BASELINE config -- the fused kernel
+        general = layer_head_mask is not None or output_attentions or (self.training and self.dropout > 0)
         bsz, tgt_len, _ = hidden_states.shape
         src_len = neighbor_embeds.shape[1]
         if neighbor_attention_mask is None:
@@ -167,8 +166,13 @@ class MPTAttention(nn.Module):
         q = ops.linear(hidden_states, self.q_proj.weight, self.q_proj.bias, out_scale=self.scaling)
         k = ops.linear(neighbor_embeds, self.k_proj.weight, self.k_proj.bias)
         v = ops.linear(neighbor_embeds, self.v_proj.weight, self.v_proj.bias)
-        o = ops.xattn_core(q, k, v, key_valid, self.num_heads)
-        return ops.linear(o, self.out_proj.weight, self.out_proj.bias), None, None
+        attn_w = None
+        if general:
+            o, attn_w = ops.attn_general(q, k, v, key_valid, self.num_heads, causal=False, head_mask=layer_head_mask, p_drop=self.dropout,
+                                         training=self.training, output_attentions=output_attentions)
+        else:
+            o = ops.xattn_core(q, k, v, key_valid, self.num_heads)
+        return ops.linear(o, self.out_proj.weight, self.out_proj.bias), attn_w, None
 
     def _frozen_qkv(self):
         """[3d, d] weight / [3d] bias = (q_proj * scaling | k_proj | v_proj) when the three projections are frozen (the
@@ -195,6 +199,8 @@ class MPTAttention(nn.Module):
         q, k, v = self.q_proj, self.k_proj, self.v_proj
         if not (hasattr(q, "lora_A") and hasattr(v, "lora_A") and type(k) is nn.Linear) or q.r != v.r or q.scaling != v.scaling:
             return None
+        if self.training and (getattr(q, "lora_dropout", 0.0) > 0.0 or getattr(v, "lora_dropout", 0.0) > 0.0):
+            return None                      # lora_dropout: each adapted projection runs its own (unfused) forward
         ps = (q.base_layer.weight, k.weight, v.base_layer.weight, q.base_layer.bias, k.bias, v.base_layer.bias)
         if any(p is None or p.requires_grad for p in ps):
             return None
@@ -214,9 +220,24 @@ class MPTAttention(nn.Module):
         if attention_mask is None or attention_mask.dim() != 2:
             raise ValueError("self-attention takes the [bsz, seq_len] key mask (causality is implied); additive 4-D masks are "
                              f"not materialised on this path (got {None if attention_mask is None else tuple(attention_mask.shape)})")
-        if layer_head_mask is not None or output_attentions or (self.training and self.dropout > 0):
-            raise ValueError("layer_head_mask / output_attentions / attention dropout are not available on the fused self-attention kernels")
+        general = layer_head_mask is not None or output_attentions or (self.training and self.dropout > 0)
+        if general and past_key_value is not None:
+            raise ValueError("layer_head_mask / output_attentions / attention dropout together with a key / value prefix (prefix tuning) "
+                             "are not implemented")
         fused = self._frozen_qkv()
+        if general:
+            # reference :237-256 on the self-attention call site: separate q / k / v (the fused-QKV node has no general core), the
+            # general HIP core with the causal AND key mask
+            d = hidden_states.shape[-1]
+            if fused is not None:
+                qkv = ops.frozen_linear(hidden_states, *fused)
+                q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+            else:
+                q = _lin(self.q_proj, hidden_states) * self.scaling
+                k, v = _lin(self.k_proj, hidden_states), _lin(self.v_proj, hidden_states)
+            o, attn_w = ops.attn_general(q, k, v, attention_mask, H, causal=True, head_mask=layer_head_mask, p_drop=self.dropout,
+                                         training=self.training, output_attentions=output_attentions)
+            return _lin(self.out_proj, o), attn_w, None
         if past_key_value is not None:
             # prefix tuning (peft hands the learned per-layer key/value prefix to HF as past_key_values): P extra keys / values in
             # front of the layer's own, visible to every query; attention_mask is the [bsz, P + seq_len] key mask
@@ -498,9 +519,8 @@ class MPTDecoder(MPTPreTrainedModel):
         elif attention_mask.shape[1] != seq_length + prefix_len:
             raise ValueError(f"The provided attention mask has length {attention_mask.shape[1]}, but its length should be "
                              f"{seq_length + prefix_len} (sum of the lengths of current and past inputs)")
-        if output_attentions or head_mask is not None or (self.training and self.config.attention_dropout > 0):
-            raise ValueError("output_attentions / head_mask / attention_dropout need materialised attention weights, which the fused "
-                             "self-attention kernels never form")
+        # (output_attentions / head_mask / attention_dropout > 0: the layers route their attention to the general HIP core,
+        # ops.attn_general -- reference :237-256; the fused kernels keep every other call)
         # The [B,1,T,T] additive mask (:455-476) is never built: the flash kernels take the [B,T] key mask, causality implied.
         # That equals the reference's finfo.min arithmetic as long as no query row is fully masked, i.e. key 0 of every sample
         # is valid -- true for the right-padded sequences of wikiweb2m/data.py:321-333.  The collate can vouch for it on the
@@ -542,9 +562,7 @@ class MPTDecoder(MPTPreTrainedModel):
                 neighbor_idx = (idx + 1) // self.neighbor_layer_wise - 1
                 layer_outputs = self.neighbor_layers[neighbor_idx](
                     hidden_states, attention_mask=causal_attention_mask, neighbor_embeds=neighbor_embeds,
-                    neighbor_attention_mask=key_valid, layer_head_mask=None, output_attentions=False)
-                if output_attentions:
-                    layer_outputs = layer_outputs + (None,)
+                    neighbor_attention_mask=key_valid, layer_head_mask=lhm, output_attentions=output_attentions)     # (:613-623)
             hidden_states = layer_outputs[0]
             if output_attentions:
                 all_self_attns += (layer_outputs[1],)
@@ -722,10 +740,15 @@ class _PatchEmbedLinear(nn.Conv2d):
         n, c, hh, ww = x.shape
         cols = x.view(n, c, hh // p, p, ww // p, p).permute(0, 2, 4, 1, 3, 5).reshape(n * (hh // p) * (ww // p), c * p * p)
         w = self.weight.view(self.out_channels, -1)
-        if cols.is_cuda and not torch.is_grad_enabled():
-            y = ops.gemm_nt(cols.contiguous(), w, self.bias)        # frozen encoder: forward only, on the HIP GEMM
+        if cols.is_cuda:
+            # frozen encoder: forward only, on the HIP GEMM.  A caller that wants gradients through the patch embedding on the GPU
+            # gets an error, not a silent library GEMM (the reference freezes the visual model: modelling_cross_attention.py:934-939)
+            if torch.is_grad_enabled() and (cols.requires_grad or w.requires_grad or (self.bias is not None and self.bias.requires_grad)):
+                raise ValueError("_PatchEmbedLinear: the patch embedding of the frozen visual encoder has no HIP backward; run it under "
+                                 "torch.no_grad() or freeze it (requires_grad_(False))")
+            y = ops.gemm_nt(cols.contiguous(), w, self.bias)
         else:
-            y = F.linear(cols, w, self.bias)
+            y = F.linear(cols, w, self.bias)                        # CPU tensors only (the reference's CPU plumbing path, BASELINE config 1)
         return y.view(n, hh // p, ww // p, self.out_channels).permute(0, 3, 1, 2)
 
 

@@ -36,8 +36,9 @@ class LoRALinear(nn.Module):
 
     def __init__(self, base: nn.Linear, r: int, alpha: float, dropout: float = 0.0):
         super().__init__()
-        if dropout:
-            raise ValueError("lora_dropout > 0 is not implemented in the fused LoRA kernel (reference default is 0.0)")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"lora_dropout must be in [0, 1), got {dropout}")
+        self.lora_dropout = float(dropout)          # peft: dropout on the INPUT of the low-rank branch only, in training
         self.base_layer = base
         for p in self.base_layer.parameters():
             p.requires_grad = False
@@ -57,6 +58,16 @@ class LoRALinear(nn.Module):
     def forward(self, x, out_scale=1.0):
         """out_scale: a constant factor on the whole output (attention's D^-1/2 on an adapted q_proj), applied in the GEMM epilogues
         instead of a separate pass over [B, T, d]."""
+        if self.training and self.lora_dropout > 0.0:
+            # lora_dropout > 0 (reference model/modelling_self_attention.py:80-87 -> peft: result = base(x) + B(A(dropout(x))) * scaling;
+            # the reference's default is 0.0 and no BASELINE config sets it): the branch sees a dropped copy of x, so the one-call fused
+            # kernel (one x for both products) does not apply -- frozen base GEMM + the two skinny GEMMs, all on the HIP kernels;
+            # dropout(x) = the gated-residual kernel with a zero residual and no gate (counter-hash mask, regenerated in backward)
+            xd = ops.gated_residual(torch.zeros_like(x), x, None, self.lora_dropout, True)
+            base = ops.frozen_linear(x, self.base_layer.weight, self.base_layer.bias)
+            low = ops.linear(ops.linear(xd, self.lora_A, None), self.lora_B, None)
+            y = torch.add(base, low, alpha=self.scaling)
+            return y if out_scale == 1.0 else y * out_scale
         return ops.lora_linear(x, self.base_layer.weight, self.base_layer.bias, self.lora_A, self.lora_B, self.scaling, out_scale)
 
 

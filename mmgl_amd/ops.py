@@ -63,6 +63,74 @@ def xattn_core(q, k, v, key_valid, num_heads):
     return _XAttnCore.apply(q, k, v, key_valid.contiguous(), num_heads)
 
 
+# ------------------------------------------------------------------------------------------ general (unfused) attention core
+class _AttnGeneral(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, key_valid, head_mask, num_heads, causal, p_drop, seed, want_probs):
+        require_cuda(q, k, v, key_valid)
+        B, T, d = q.shape
+        S = k.shape[1]
+        D = d // num_heads
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out = torch.empty_like(q)
+        lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=q.device)
+        probs = torch.empty(B, num_heads, T, S, dtype=q.dtype, device=q.device) if want_probs else None
+        hm = None if head_mask is None else head_mask.detach().to(device=q.device, dtype=torch.float32).contiguous()
+        _lib.call("mmgl_attn_general_fwd", dict(flops=4.0 * B * T * S * d), ptr(q), ptr(k), ptr(v), ptr(key_valid), ptr(hm) if hm is not None else None,
+                  ptr(out), ptr(probs) if probs is not None else None, ptr(lse), B, num_heads, T, S, D, int(causal), float(p_drop), int(seed),
+                  dtype_code(q), stream_ptr())
+        ctx.save_for_backward(q, k, v, key_valid, lse, hm)
+        ctx.cfg = (num_heads, int(causal), float(p_drop), int(seed))
+        if probs is not None:
+            ctx.mark_non_differentiable(probs)
+            return out, probs
+        return out, None
+
+    @staticmethod
+    def backward(ctx, dout, _dprobs):
+        q, k, v, key_valid, lse, hm = ctx.saved_tensors
+        H, causal, p_drop, seed = ctx.cfg
+        B, T, d = q.shape
+        S = k.shape[1]
+        D = d // H
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        nbytes = lib().mmgl_attn_general_bwd_workspace(B, H, T)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        _lib.call("mmgl_attn_general_bwd", dict(flops=10.0 * B * T * S * d), ptr(dout), ptr(q), ptr(k), ptr(v), ptr(lse), ptr(key_valid),
+                  ptr(hm) if hm is not None else None, ptr(dq), ptr(dk), ptr(dv), ptr(ws), nbytes, B, H, T, S, D, causal, p_drop, seed,
+                  dtype_code(q), stream_ptr())
+        return dq, dk, dv, None, None, None, None, None, None, None
+
+
+def attn_general(q, k, v, key_valid, num_heads, causal=False, head_mask=None, p_drop=0.0, training=False, seed=None, output_attentions=False):
+    """The attention core with the options the fused kernels leave out (reference model/modelling_cross_attention.py:206-271):
+    `head_mask` [H] scales the probabilities of each head (:237-244), `output_attentions` also returns them as [B,H,T,S] -- head-masked,
+    before dropout, not differentiable (:246-254) --, `p_drop` drops probabilities in training (:256; counter hash of (seed, index),
+    regenerated in backward).  q [B,T,d] is already scaled; causal = the decoder's self-attention (S == T).  Returns (out, probs | None)."""
+    if q.dim() != 3 or k.shape != v.shape or k.dim() != 3 or q.shape[0] != k.shape[0] or q.shape[2] != k.shape[2]:
+        raise ValueError(f"attn_general: incompatible shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+    if q.shape[2] % num_heads:
+        raise ValueError(f"embed_dim must be divisible by num_heads (got `embed_dim`: {q.shape[2]} and `num_heads`: {num_heads}).")
+    if key_valid.shape != k.shape[:2]:
+        raise ValueError(f"Attention mask should be of size {tuple(k.shape[:2])}, but is {tuple(key_valid.shape)}")
+    if head_mask is not None and tuple(head_mask.shape) != (num_heads,):
+        raise ValueError(f"Head mask for a single layer should be of size {(num_heads,)}, but is {tuple(head_mask.shape)}")
+    if key_valid.dtype != torch.uint8:
+        key_valid = key_valid.to(torch.uint8)
+    p = float(p_drop) if training else 0.0
+    if p > 0.0 and seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return _AttnGeneral.apply(q, k, v, key_valid.contiguous(), head_mask, num_heads, bool(causal), p, int(seed or 0), bool(output_attentions))
+
+
+def attn_dropout_mask(B, H, T, S, p_drop, seed, device):
+    """The keep mask attn_general uses for (p_drop, seed), as uint8 [B,H,T,S]: test / debug aid."""
+    m = torch.empty(B, H, T, S, dtype=torch.uint8, device=device)
+    _lib.call("mmgl_attn_dropout_mask", None, ptr(m), B, H, T, S, float(p_drop), int(seed), stream_ptr())
+    return m
+
+
 # ------------------------------------------------------------------------------------------ causal self-attention
 class _SelfAttnCore(torch.autograd.Function):
     @staticmethod

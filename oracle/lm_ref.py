@@ -73,9 +73,13 @@ def learned_position_ids(attention_mask: torch.Tensor) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- attention
 def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, add_mask: Optional[torch.Tensor],
-                   num_heads: int) -> torch.Tensor:
+                   num_heads: int, head_mask: Optional[torch.Tensor] = None, keep: Optional[torch.Tensor] = None,
+                   p_drop: float = 0.0, return_probs: bool = False):
     """softmax(max(QK^T + M, finfo.min)) V on [B,T,d] / [B,S,d] tensors; q is already scaled
-    (reference :206-271).  Returns [B,T,d] with heads merged."""
+    (reference :206-271).  Returns [B,T,d] with heads merged.
+    Options of :237-256 (pinned by tests/golden/g10_attention_options_*.npz): `head_mask` [H] scales each head's probabilities
+    (:237-244); `return_probs` also returns them as [B,H,T,S], head-masked and BEFORE dropout (:246-254); `keep` [B,H,T,S] (bool)
+    with `p_drop` is the attention-probability dropout of :256 with an explicit mask, probs * keep / (1 - p_drop)."""
     B, T, d = q.shape
     S = k.shape[1]
     D = d // num_heads
@@ -91,20 +95,29 @@ def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, add_mask: 
         # fully-masked sample gets 0.5x dQ / dK.  The HIP backward reproduces this.
         scores = torch.maximum(scores, torch.tensor(torch.finfo(scores.dtype).min, dtype=scores.dtype))
     probs = torch.softmax(scores, dim=-1)
+    if head_mask is not None:
+        probs = head_mask.view(1, -1, 1, 1) * probs
+    weights = probs
+    if keep is not None and p_drop > 0.0:
+        probs = probs * keep.to(probs.dtype) / (1.0 - p_drop)
     out = probs @ vh                                         # [B,H,T,D]
-    return out.permute(0, 2, 1, 3).reshape(B, T, d)
+    out = out.permute(0, 2, 1, 3).reshape(B, T, d)
+    return (out, weights) if return_probs else out
 
 
 def attention(p: Dict[str, torch.Tensor], pre: str, hidden: torch.Tensor, add_mask: Optional[torch.Tensor],
-              num_heads: int, kv_source: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """MPTAttention.forward (:179-275).  kv_source=None => self-attention."""
+              num_heads: int, kv_source: Optional[torch.Tensor] = None, head_mask: Optional[torch.Tensor] = None,
+              keep: Optional[torch.Tensor] = None, p_drop: float = 0.0, return_probs: bool = False):
+    """MPTAttention.forward (:179-275).  kv_source=None => self-attention.  head_mask / keep / p_drop / return_probs: attention_core."""
     d = hidden.shape[-1]
     D = d // num_heads
     src = hidden if kv_source is None else kv_source
     q = F.linear(hidden, p[pre + "q_proj.weight"], p.get(pre + "q_proj.bias")) * (D ** -0.5)
     k = F.linear(src, p[pre + "k_proj.weight"], p.get(pre + "k_proj.bias"))
     v = F.linear(src, p[pre + "v_proj.weight"], p.get(pre + "v_proj.bias"))
-    o = attention_core(q, k, v, add_mask, num_heads)
+    o = attention_core(q, k, v, add_mask, num_heads, head_mask, keep, p_drop, return_probs)
+    if return_probs:
+        return F.linear(o[0], p[pre + "out_proj.weight"], p.get(pre + "out_proj.bias")), o[1]
     return F.linear(o, p[pre + "out_proj.weight"], p.get(pre + "out_proj.bias"))
 
 

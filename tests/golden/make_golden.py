@@ -173,6 +173,63 @@ def golden_attention(xa):
                    **{k: v.grad for k, v in attn.named_parameters()}))
 
 
+def golden_attention_options(xa):
+    """G10: MPTAttention with the options of :237-256 switched on -- layer_head_mask, output_attentions, attention-probability dropout in
+    training mode -- on both call sites (cross: key mask incl. a fully-masked sample; self: causal + right padding).  The dropout mask
+    is fixed: nn.functional.dropout is replaced, for the duration of the reference's forward, by `x * keep / (1 - p)` with a saved
+    Bernoulli `keep` (the reference draws its mask from torch's RNG stream, which no other implementation can replay); everything else
+    -- where the mask is applied, in which layout, what is returned -- is the reference's own code."""
+    import torch.nn.functional as F
+    torch.manual_seed(10)
+    cfg = xa.MPTConfig(mpt_args(), tiny_opt_config())
+    H, D, p = 4, 16, 0.25
+    real_dropout = F.dropout
+    for name, cross, B, T, S in (("cross", True, 3, 16, 12), ("self", False, 2, 16, 16)):
+        attn = xa.MPTAttention(cfg, cross_attention=cross)
+        for prm in attn.parameters():
+            torch.nn.init.normal_(prm, std=0.15)
+        attn.dropout = p
+        attn.train()
+        hidden = torch.randn(B, T, H * D, requires_grad=True)
+        head_mask = torch.tensor([1.0, 0.0, 0.5, 2.0])
+        keep = (torch.rand(B * H, T, S) >= p)
+
+        def fixed_dropout(x, p=0.5, training=True, inplace=False, _keep=keep, _p=p):
+            assert training and tuple(x.shape) == tuple(_keep.shape) and abs(p - _p) < 1e-12
+            return x * _keep.to(x.dtype) / (1.0 - _p)
+
+        if cross:
+            ne = torch.randn(B, S, H * D, requires_grad=True)
+            valid = torch.ones(B, S, dtype=torch.bool)
+            valid[0, 7:] = False
+            valid[1, :] = False
+            valid[2, ::3] = False
+            m4 = xa._expand_mask(valid, hidden.dtype, tgt_len=T)
+            kw = dict(neighbor_embeds=ne, neighbor_attention_mask=m4)
+        else:
+            ne = None
+            valid = torch.ones(B, T, dtype=torch.bool)
+            valid[1, 11:] = False
+            m4 = xa._expand_mask(valid, hidden.dtype, tgt_len=T) + xa._make_causal_mask((B, T), hidden.dtype, device=hidden.device)
+            kw = dict(attention_mask=m4)
+        F.dropout = fixed_dropout
+        torch.nn.functional.dropout = fixed_dropout
+        try:
+            out, attn_w, _ = attn(hidden, layer_head_mask=head_mask, output_attentions=True, **kw)
+        finally:
+            F.dropout = real_dropout
+            torch.nn.functional.dropout = real_dropout
+        w = torch.randn_like(out)
+        (out * w).sum().backward()
+        ins = dict(hidden=hidden, valid=valid, w=w, head_mask=head_mask, keep=keep.reshape(B, H, T, S))
+        grads = dict(hidden=hidden.grad, **{k: v.grad for k, v in attn.named_parameters()})
+        if cross:
+            ins["neighbor_embeds"] = ne
+            grads["neighbor_embeds"] = ne.grad
+        save(f"g10_attention_options_{name}.npz", dict(B=B, H=H, T=T, S=S, D=D, p_drop=p, scalar="sum(out*w)"),
+             p={k: v for k, v in attn.state_dict().items()}, **{"in": ins}, out=dict(out=out, attn_weights=attn_w), grad=grads)
+
+
 def golden_layer(xa):
     """G5: MPTDecoderLayer(cross, flamingo) fwd+bwd, pre-LN and post-LN."""
     for tag, pre_ln in (("preln", True), ("postln", False)):
@@ -321,6 +378,7 @@ def main():
     torch.set_num_threads(4)
     xa = _load("ref_xattn", f"{REF}/model/modelling_cross_attention.py")
     golden_attention(xa)
+    golden_attention_options(xa)
     golden_layer(xa)
     golden_lm_raw(xa)
     golden_wrapper(xa)

@@ -299,20 +299,21 @@ def test_dynamic_tile_schedule_one_to_three_rounds(M):
 
 
 def test_dynamic_tile_schedule_is_bound_to_one_stream():
-    """include/mmgl_hip.h: while a tile counter is set, the device's persistent-GEMM launches belong to ONE stream (the counters are
-    shared); a launch on a second stream is refused with MMGL_ERR_INVALID (-> ValueError) instead of corrupting both schedules, and
-    setting the counter again releases the binding."""
+    """include/mmgl_hip.h: while a tile counter is set, the device's counters belong to ONE stream (they are shared); a launch on a
+    second stream runs on the static schedule instead (it never touches the counters), so side-stream work stays legal and correct;
+    setting the counter again releases the binding.  (MMGL_GEMM_STRICT_STREAM=1 turns the side-stream launch into MMGL_ERR_INVALID.)"""
     from mmgl_amd import ops
     x, W, b, _, _ = _mk(8192, 2048, 2048, seed=5, bias=True)
     y0 = ops.gemm_nt(x, W, b)
     side = torch.cuda.Stream()
-    ops.gemm_dynamic_schedule(True)
+    ctr = ops.gemm_dynamic_schedule(True)
     try:
         y1 = ops.gemm_nt(x, W, b)                    # binds the counters to the current stream
         torch.cuda.synchronize()
         with torch.cuda.stream(side):
-            with pytest.raises(ValueError, match="bound to another stream"):
-                ops.gemm_nt(x, W, b)
+            y5 = ops.gemm_nt(x, W, b)                # another stream: static schedule, counters untouched
+        torch.cuda.synchronize()
+        assert int(ctr.abs().sum()) == 0, ctr.tolist()
         y2 = ops.gemm_nt(x, W, b)                    # the bound stream keeps working
         ops.gemm_dynamic_schedule(True)              # set again: binding released
         torch.cuda.synchronize()
@@ -324,7 +325,19 @@ def test_dynamic_tile_schedule_is_bound_to_one_stream():
     with torch.cuda.stream(side):                    # static schedule: any stream
         y4 = ops.gemm_nt(x, W, b)
     torch.cuda.synchronize()
-    assert all(torch.equal(y0, y) for y in (y1, y2, y3, y4))
+    assert all(torch.equal(y0, y) for y in (y1, y2, y3, y4, y5))
+
+
+def test_four_wave_gemm_matches_torch():
+    """gemm4w.hip (the 512-register, four-wave kernel of DESIGN 9.6c iv-a; measured 0.87x gemm8p and not adopted) stays correct: the
+    probe's checks -- ragged rows / columns, lm_head's 96-column last tile column, bias, scale -- in a process that selects it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MMGL_GEMM_4W="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "gemm4w_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_dynamic_tile_schedule_reaches_the_backward_thread():

@@ -36,6 +36,33 @@ def test_g4_fully_masked_row_is_uniform():
     assert_close(out, v.mean(dim=1, keepdim=True).expand(1, 5, 64), 1e-6, "uniform")
 
 
+def test_g10_attention_options_fwd_bwd():
+    """The options of MPTAttention.forward :237-256 -- layer_head_mask, output_attentions, attention-probability dropout (with the
+    fixture's explicit mask) -- on both call sites, against outputs of the reference itself."""
+    for name in ("cross", "self"):
+        fx = Fixture(f"g10_attention_options_{name}.npz")
+        H, pd = fx.meta["H"], fx.meta["p_drop"]
+        hidden = fx.inp["hidden"].clone().requires_grad_()
+        p = {k: v.clone().requires_grad_() for k, v in fx.p.items()}
+        T = hidden.shape[1]
+        if name == "cross":
+            ne = fx.inp["neighbor_embeds"].clone().requires_grad_()
+            m4 = lm_ref.expand_mask(fx.inp["valid"], hidden.dtype, T)
+        else:
+            ne = None
+            m4 = lm_ref.decoder_self_mask(fx.inp["valid"], hidden.dtype)
+        out, w = lm_ref.attention(p, "", hidden, m4, H, kv_source=ne, head_mask=fx.inp["head_mask"], keep=fx.inp["keep"], p_drop=pd,
+                                  return_probs=True)
+        assert_close(out, fx.out["out"], TOL, f"{name} out")
+        assert_close(w, fx.out["attn_weights"], TOL, f"{name} attn_weights")
+        (out * fx.inp["w"]).sum().backward()
+        assert_close(hidden.grad, fx.grad["hidden"], TOL, f"{name} d hidden")
+        if ne is not None:
+            assert_close(ne.grad, fx.grad["neighbor_embeds"], TOL, f"{name} d neighbor_embeds")
+        for k in p:
+            assert_close(p[k].grad, fx.grad[k], TOL, f"{name} d {k}")
+
+
 def _layer_cfg(meta):
     return lm_ref.LMConfig(vocab_size=128, hidden_size=meta["d"], num_attention_heads=meta["H"], ffn_dim=meta["ffn"],
                            num_hidden_layers=1, word_embed_proj_dim=meta["d"], do_layer_norm_before=meta["pre_ln"])
