@@ -196,13 +196,12 @@ inline constexpr int tune_gemm_mid() { return 1; }       // 1: gemm_mid_kernel t
 inline int gemm8p_row_split(int M, int N, int K, int ldx, int ldw, int ldy) {
     const int G = gemm8p_num_cu(), tm = cdiv(M, 256), tn = cdiv(N, 256);
     const int rounds = tm * tn / G, rem = tm * tn % G;
-    // round 5: also ANY number of whole rounds plus a remainder of a third to a half of a round (config 4 at B = 64: [45056, 2048]
-    // = 1408 tiles = 5.5 rounds): too big for the K-split remainder plan (gemm8p_plan: at least 3 splits), and as 128x128 tiles it is at
-    // most one round of the few-tile kernel's 512 slots (~0.73 of a persistent round instead of a whole one).  MMGL_GEMM_ROWSPLIT_BAND=0: off.
-    static const bool band = !(getenv("MMGL_GEMM_ROWSPLIT_BAND") && atoi(getenv("MMGL_GEMM_ROWSPLIT_BAND")) == 0);
-    const bool small_tail = rounds >= 1 && rounds <= 3 && rem > 0 && rem <= G / 4;
-    const bool half_tail = band && rounds >= 1 && rem > G / 3 && rem <= G / 2;
-    if (!(small_tail || half_tail) || (rounds * G) % tn) return 0;
+    // (round 5 tried the same split for ANY number of whole rounds plus a remainder of a third to a half of a round -- config 4 at
+    // B = 64: [45056, 2048] = 5.5 rounds, the remainder as one round of the few-tile kernel: mmgl_gemm_nt 310.6 -> 307.8 ms per step,
+    // step 282.0 -> 282.3 ms: nothing, removed.  A partial round costs what it costs at K = 2048: a tile is 45 us, and every way of
+    // cutting the remainder finer -- K splits with fp32 partial tiles, 128x128 tiles at 0.68 of the big kernel's rate -- pays about
+    // what it saves; bench.py prints `batch_sweep` instead of choosing batches around it)
+    if (rounds < 1 || rounds > 3 || rem == 0 || rem > G / 4 || (rounds * G) % tn) return 0;
     const int m1 = rounds * G / tn * 256;
     return (m1 > 0 && m1 < M && gemm_mid_supported(M - m1, N, K, ldx, ldw, ldy)) ? m1 : 0;
 }

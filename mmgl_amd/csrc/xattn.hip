@@ -535,171 +535,6 @@ __global__ __launch_bounds__(64) void xattn_bwd_dkv_kernel(const T* __restrict__
     }
 }
 
-// bf16, D <= 64: one wave per (batch, head, 64-key group, T-chunk), the structure of selfattn_bwd_dkv64_kernel (selfattn.hip):
-// K / V fragments loaded once into registers, Q / dO row fragments + LSE + delta requested one tile ahead into a second
-// register set (loop unrolled by two, the sets swap roles), branch-free body (buffer-descriptor bounds, masks as selects
-// feeding exp2(-inf) = 0), Q^T / dO^T from the wave-private tile via ds_read_b64_tr_b16.  Same fp32 partial layout as above.
-template <int D, int NSBW>
-__global__ __launch_bounds__(64) void xattn_bwd_dkv64_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ q,
-                                                             const bf16* __restrict__ k, const bf16* __restrict__ v,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                             const uint8_t* __restrict__ valid, float* __restrict__ dk_part,
-                                                             float* __restrict__ dv_part, int B, int H, int T_, int S,
-                                                             int nsg, int rows_per_chunk, int nchunk) {
-    typedef bf16 T;
-    typedef XC<T, D, NSBW> C;
-    constexpr int KW = 16 * NSBW;                  // keys per wave: 64 up to D = 64, 32 at D = 128
-    typedef bf16x8 v8;
-    constexpr int LDT = C::DPAD + 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Qt = (T*)smem;
-    T* Gt = Qt + 32 * LDT;
-    const int lane = threadIdx.x, x = lane & 15, g = lane >> 4;
-    const int vid = xcd_remap(blockIdx.x, B * H * nsg * nchunk);
-    const int chunk = vid % nchunk;
-    const int sg = (vid / nchunk) % nsg;
-    const int bh = vid / (nchunk * nsg);
-    const int b = bh / H, h = bh % H;
-    const size_t HD = (size_t)H * D;
-    const int s0 = sg * KW;
-    const int row_begin = chunk * rows_per_chunk, row_end = min(row_begin + rows_per_chunk, T_);
-
-    const uint32_t rb = (uint32_t)(HD * sizeof(T));
-    const uint32_t slab_t = (uint32_t)(((size_t)(T_ - 1) * HD + D) * sizeof(T)), slab_s = (uint32_t)(((size_t)(S - 1) * HD + D) * sizeof(T));
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q + (size_t)b * T_ * HD + h * D, slab_t);
-    const __amdgpu_buffer_rsrc_t rg = make_rsrc(dout + (size_t)b * T_ * HD + h * D, slab_t);
-    const __amdgpu_buffer_rsrc_t rk = make_rsrc(k + (size_t)b * S * HD + h * D, slab_s);
-    const __amdgpu_buffer_rsrc_t rv = make_rsrc(v + (size_t)b * S * HD + h * D, slab_s);
-    const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
-    const __amdgpu_buffer_rsrc_t rd = make_rsrc(delta + (size_t)bh * T_, (uint32_t)(T_ * sizeof(float)));
-
-    bool any = false;
-    for (int s = lane; s < S; s += 64) any |= valid[(size_t)b * S + s] != 0;
-    const bool any_valid = __ballot(any) != 0ull;
-    const float uni = 1.f / (float)S, tie = any_valid ? 1.f : 0.5f;
-
-    v8 kf[NSBW][C::NDC], vf[NSBW][C::NDC];
-    float kbias[NSBW], kuni[NSBW];                       // valid key: 0 / -inf;  existing key: 1/S / 0 (sample without any valid key)
-#pragma unroll
-    for (int sbl = 0; sbl < NSBW; ++sbl) {
-        const int s = s0 + sbl * 16 + x;
-        kbias[sbl] = (s < S && valid[(size_t)b * S + min(s, S - 1)] != 0) ? 0.f : -INFINITY;
-        kuni[sbl] = s < S ? uni : 0.f;
-#pragma unroll
-        for (int dc = 0; dc < C::NDC; ++dc) {
-            kf[sbl][dc] = buf_load8<T>(rk, row_off<T, C>(s, rb, dc * 32 + g * 8));
-            vf[sbl][dc] = buf_load8<T>(rv, row_off<T, C>(s, rb, dc * 32 + g * 8));
-        }
-    }
-    f32x4 dva[C::NDB][NSBW], dka[C::NDB][NSBW];
-#pragma unroll
-    for (int db = 0; db < C::NDB; ++db)
-#pragma unroll
-        for (int sbl = 0; sbl < NSBW; ++sbl) { dva[db][sbl] = vzero<f32x4>(); dka[db][sbl] = vzero<f32x4>(); }
-
-    auto request = [&](int tbase, v8 (&qn)[2][C::NDC], v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-#pragma unroll
-            for (int dc = 0; dc < C::NDC; ++dc) {
-                qn[tb][dc] = buf_load8<T>(rq, row_off<T, C>(tbase + tb * 16 + x, rb, dc * 32 + g * 8));
-                gn[tb][dc] = buf_load8<T>(rg, row_off<T, C>(tbase + tb * 16 + x, rb, dc * 32 + g * 8));
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t o = (uint32_t)(tbase + tb * 16 + g * 4 + r) * 4u;
-                ln[tb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, o, 0, 0));
-                dn[tb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, o, 0, 0));
-            }
-        }
-    };
-    auto step = [&](int t0, v8 (&qa)[2][C::NDC], v8 (&ga)[2][C::NDC], float (&la)[2][4], float (&da)[2][4], v8 (&qn)[2][C::NDC],
-                    v8 (&gn)[2][C::NDC], float (&ln)[2][4], float (&dn)[2][4]) __attribute__((always_inline)) {
-        request(t0 + 32, qn, gn, ln, dn);
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int dc = 0; dc < C::NDC; ++dc) {
-                *(v8*)(Qt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = qa[tb][dc];
-                *(v8*)(Gt + (tb * 16 + x) * LDT + dc * 32 + g * 8) = ga[tb][dc];
-            }
-        float lt[2][4], rowu[2][4];
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool tv = t0 + tb * 16 + g * 4 + r < row_end;      // rows of the next chunk / past T: p = 0
-                lt[tb][r] = tv ? la[tb][r] * LOG2E : INFINITY;
-                rowu[tb][r] = tv ? 1.f : 0.f;
-            }
-        v8 pB[NSBW], dsB[NSBW];
-#pragma unroll
-        for (int sbl = 0; sbl < NSBW; ++sbl) {
-            f32x4 pr[2], dsr[2];
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
-                f32x4 sa = vzero<f32x4>(), pa = vzero<f32x4>();
-#pragma unroll
-                for (int dc = 0; dc < C::NDC; ++dc) {
-                    mma16(sa, qa[tb][dc], kf[sbl][dc]);
-                    mma16(pa, ga[tb][dc], vf[sbl][dc]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float p;
-                    if (any_valid) p = __builtin_amdgcn_exp2f(fmaf(sa[r], LOG2E, kbias[sbl] - lt[tb][r]));
-                    else p = kuni[sbl] * rowu[tb][r];          // every key masked: uniform over the S real keys
-                    pr[tb][r] = p;
-                    dsr[tb][r] = tie * p * (pa[r] - da[tb][r]);
-                }
-            }
-            pB[sbl] = pack8<T>(pr[0], pr[1]);
-            dsB[sbl] = pack8<T>(dsr[0], dsr[1]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int db = 0; db < C::NDB; ++db) {
-            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-            const bf16* pg = Gt + (4 * g + (x >> 2)) * LDT + db * 16 + (x & 3) * 4;
-            const bf16* pq = Qt + (4 * g + (x >> 2)) * LDT + db * 16 + (x & 3) * 4;
-            const bf16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pg);
-            const bf16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pg + 16 * LDT));
-            const bf16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pq);
-            const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pq + 16 * LDT));
-            const v8 gT = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-            const v8 qT = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-#pragma unroll
-            for (int sbl = 0; sbl < NSBW; ++sbl) {
-                mma16(dva[db][sbl], gT, pB[sbl]);
-                mma16(dka[db][sbl], qT, dsB[sbl]);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    v8 qA[2][C::NDC], gA[2][C::NDC], qB[2][C::NDC], gB[2][C::NDC];
-    float lA[2][4], dA[2][4], lB[2][4], dB[2][4];
-    request(row_begin, qA, gA, lA, dA);
-    for (int t0 = row_begin; t0 < row_end; t0 += 64) {
-        step(t0, qA, gA, lA, dA, qB, gB, lB, dB);
-        if (t0 + 32 < row_end) step(t0 + 32, qB, gB, lB, dB, qA, gA, lA, dA);
-    }
-#pragma unroll
-    for (int sbl = 0; sbl < NSBW; ++sbl) {
-        const int s = s0 + sbl * 16 + x;
-        if (s < S) {
-            const size_t off = (((size_t)chunk * B + b) * S + s) * HD + h * D + g * 4;
-#pragma unroll
-            for (int db = 0; db < C::NDB; ++db) {
-                *(f32x4*)(dk_part + off + db * 16) = dka[db][sbl];
-                *(f32x4*)(dv_part + off + db * 16) = dva[db][sbl];
-            }
-        }
-    }
-}
-
 // ============================================================================================ backward, fused (bf16, D <= 64, S <= 64)
 // dQ, dK and dV out of ONE pass over Q and dO: a wave owns (batch, head, T-chunk) and ALL keys, streams 32-row tiles
 // (requested one tile ahead, bounds by buffer descriptors) and per tile
@@ -1300,11 +1135,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // ============================================================================================ host dispatch
 struct BwdPlan { int nsg, nchunk, rows_per_chunk; size_t delta_off, dk_off, dv_off, total; };
 
-// keys per dK/dV wave: 64 for the bf16 D <= 64 kernel, 32 for the generic one
-inline bool use_dkv64(int D, size_t esz) {
-    return esz == 2;
-}
-inline int dkv64_keys(int D) { return D <= 64 ? 64 : 32; }
+// (the two-kernel backward below the fused ones: 32 keys per dK/dV wave.  Round 5 removed its bf16-only 64-key variant,
+// xattn_bwd_dkv64_kernel: since the one-pass kernels took every BASELINE shape it only served bf16 with S > 128 or head_dim 16 / 32
+// with S > 64, which the generic kernel covers)
 inline constexpr bool use_fused_bwd() { return true; }
 
 // the multi-wave one-pass backward (xattn_bwd_fusedw_kernel): bf16, head_dim 64 / 128, up to 128 keys, and not the shapes the one-wave
@@ -1314,7 +1147,7 @@ inline bool use_fusedw(int S, int D, size_t esz) { return esz == 2 && S <= 128 &
 BwdPlan bwd_plan(int B, int H, int T, int S, int D, size_t esz = 2) {
     BwdPlan p;
     const bool fw = use_fusedw(S, D, esz);
-    p.nsg = fw ? 1 : use_dkv64(D, esz) ? (S + dkv64_keys(D) - 1) / dkv64_keys(D) : (S + 31) / 32;
+    p.nsg = fw ? 1 : (S + 31) / 32;
     long units = (long)B * H * p.nsg;
     // fusedw: one workgroup per CU (LDS); a chunk costs a set of fp32 dK / dV partials, so chunks only while (batch, head) pairs
     // alone do not fill the chip
@@ -1458,20 +1291,7 @@ int launch_bwd(const void* dout, const void* q, const void* k, const void* v, co
                            (const T*)v, lse, valid, (T*)dq, delta, B, H, T_, S, rpw, nchunk);
         MMGL_CHECK_LAUNCH("xattn_bwd_dq");
     }
-    bool done64 = false;
-    if constexpr (sizeof(T) == 2) {
-        if (use_dkv64(D, sizeof(T))) {
-            constexpr int NSBW = D <= 64 ? 4 : 2;
-            typedef XC<bf16, D, NSBW> C4;
-            const size_t lds = sizeof(bf16) * 2 * 32 * (C4::DPAD + 16);
-            hipLaunchKernelGGL((xattn_bwd_dkv64_kernel<D, NSBW>), dim3(B * H * p.nsg * p.nchunk), dim3(64), lds, st, (const bf16*)dout,
-                               (const bf16*)q, (const bf16*)k, (const bf16*)v, lse, delta, valid, dkp, dvp, B, H, T_, S, p.nsg,
-                               p.rows_per_chunk, p.nchunk);
-            MMGL_CHECK_LAUNCH("xattn_bwd_dkv64");
-            done64 = true;
-        }
-    }
-    if (!done64) {
+    {
         typedef XC<T, D, 2> C2;
         constexpr int DLD = C2::DPAD + (sizeof(T) == 2 ? 8 : 4);
         size_t lds = sizeof(T) * (2 * C2::ROWIMG + 2 * 32 * DLD);

@@ -256,8 +256,8 @@ def test_full_size_step_matches_cpu_oracle(name, nsamp):
     torch.set_num_threads(min(32, torch.get_num_threads()))
     sd = {k: v.detach().float() for k, v in model.state_dict().items()}
     gates = [k for k, p in model.named_parameters() if p.requires_grad and (k.endswith("gating1") or k.endswith("gating2"))]
-    probes = gates + ["text_embeddings.bias", "visual_embeddings.bias"]
-    for k in probes:
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad]
+    for k in trainable:                       # round 5: the oracle differentiates w.r.t. EVERY trainable parameter (was: gates + two biases)
         sd[k].requires_grad_()
     ocfg = lm_ref.LMConfig(vocab_size=lm_cfg.vocab_size, hidden_size=lm_cfg.hidden_size, num_attention_heads=lm_cfg.num_attention_heads,
                            ffn_dim=lm_cfg.ffn_dim, num_hidden_layers=lm_cfg.num_hidden_layers,
@@ -286,8 +286,25 @@ def test_full_size_step_matches_cpu_oracle(name, nsamp):
         g, r = float(p32[k].grad), float(sd[k].grad)
         print(f"   fp32 d loss / d {k}: {g:+.5e} vs {r:+.5e}")
         assert abs(g - r) <= 1e-2 * abs(r) + 2e-6, (k, g, r)
-    for k in ("text_embeddings.bias", "visual_embeddings.bias"):
-        assert_close(p32[k].grad.float().cpu(), sd[k].grad, 1e-2, f"fp32 d {k}")
+    # every trainable parameter at full size: max-norm relative error (BASELINE's measure) AND an element-wise one.  The gradients
+    # carry an ABSOLUTE noise of ~5e-4 of their largest element (fp32 summation order through 24 + 4 layers of backward: the gate
+    # gradients above agree to 3-4 digits), so an element 1000x smaller than the largest is pure noise on either side: the element-wise
+    # error is measured with a floor of 1e-2 of the tensor's largest gradient (measured round 5: 0.51 with a 1e-3 floor at
+    # neighbor_layers.0.self_attn.k_proj.weight, i.e. 5e-4 of the maximum in absolute terms)
+    from helpers import elementwise_err
+    worst = (0.0, 0.0, "")
+    for k in trainable:
+        if k in gates:
+            continue
+        g = p32[k].grad
+        assert g is not None, k
+        e_max = assert_close(g.float().cpu(), sd[k].grad, 1e-2, f"fp32 d {k}")
+        e_el = elementwise_err(g.float().cpu(), sd[k].grad, floor_frac=1e-2)
+        assert e_el <= 0.1, (k, e_el)
+        if e_max > worst[0]:
+            worst = (e_max, e_el, k)
+    print(f"   fp32 gradients of all {len(trainable)} trainable parameters vs CPU oracle: worst max-norm rel err {worst[0]:.2e} "
+          f"(element-wise {worst[1]:.2e}) at {worst[2]}")
     dev.zero_grad(set_to_none=True)
     # HIP path (bf16): forward and backward through all 28 layers
     dev = model.to(torch.bfloat16).cuda()
