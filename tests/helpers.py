@@ -39,13 +39,13 @@ def rel_err(a: torch.Tensor, b: torch.Tensor, floor: float = 1e-6) -> float:
     return (a - b).abs().max().item() / max(b.abs().max().item(), floor)
 
 
-def elementwise_err(a: torch.Tensor, b: torch.Tensor, floor_frac: float = 1e-3) -> float:
+def elementwise_err(a: torch.Tensor, b: torch.Tensor, floor_frac: float = 1e-3, abs_floor: float = 1e-6) -> float:
     """max over elements of |a - b| / (|b| + floor_frac * max|b|): an element-wise relative error (rel_err above is a max-norm measure:
     a small element of a tensor with a large maximum can be wrong by many times its own size and pass).  The floor -- a fraction of the
     tensor's largest magnitude -- keeps elements that are analytically ~0 from dividing round-off by nothing."""
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
-    floor = max(floor_frac * b.abs().max().item(), 1e-12)
+    floor = max(floor_frac * b.abs().max().item(), abs_floor)      # abs_floor: analytically-zero tensors (d k_proj.bias) are round-off on both sides
     return ((a - b).abs() / (b.abs() + floor)).max().item()
 
 
