@@ -49,6 +49,13 @@ typedef __attribute__((address_space(3))) void lds_void;
 #ifndef SA32_NS_DKV128
 #define SA32_NS_DKV128 2          // ... at head_dim 128 (one workgroup per CU: up to 4 slots of 33 KiB fit)
 #endif
+#ifndef SA32_DKV_OCC64
+#define SA32_DKV_OCC64 2          // workgroups per CU the dK / dV kernel at head_dim 64 is compiled for (176 registers: two per CU).  3 = a
+                                  // 168-register budget (9 spilled): backward 603 -> 668 us at B = 64, T = 640 (round 5): more waves, slower
+#endif
+#ifndef SA32_DQ_OCC
+#define SA32_DQ_OCC 2             // ... and the dQ kernel
+#endif
 #ifndef SA32_TRACE
 #define SA32_TRACE 0              // timing experiments only: wall-clock stamps of every workgroup of the forward kernel (MMGL_SA32_TRACE = device pointer)
 #endif
@@ -445,7 +452,7 @@ struct SA32BwdArgs {
 #define SA32_TR_READ(dst, ad, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "i"(off))
 
 template <int D>
-__global__ __launch_bounds__(256, 2) void sa32_bwd_dq_kernel(SA32BwdArgs a) {
+__global__ __launch_bounds__(256, SA32_DQ_OCC) void sa32_bwd_dq_kernel(SA32BwdArgs a) {
     typedef G32<D> G;
     constexpr int NS = SA32_NS_DQ, PD = NS - 1;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -675,7 +682,7 @@ template <int D> struct GB32 {
 };
 
 template <int D>
-__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
+__global__ __launch_bounds__(256, D == 64 ? SA32_DKV_OCC64 : 1) void sa32_bwd_dkv_kernel(SA32BwdArgs a) {
     typedef G32<D> G;
     typedef GB32<D> GB;
     constexpr int NS = GB::NS, PD = NS - 1;
