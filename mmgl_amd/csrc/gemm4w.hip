@@ -46,12 +46,6 @@ constexpr int G4_LEAD = 6;                          // units requested ahead of 
 #ifndef G4_TRACE
 #define G4_TRACE 0
 #endif
-#ifndef G4_ABLATE
-#define G4_ABLATE 0                                 // timing experiments (wrong results): 1 no LDS-DMA in the K loop, 2 no fragment reads, 4 no vmcnt wait
-#endif                                              // at the barrier, 8 no barrier, 16 no output stores
-#ifndef G4_DMA_MODE
-#define G4_DMA_MODE 0                               // 1: every wave requests in gaps 0, 4, 8, 12; 2: the waves take turns (EXEC mask); 3: one wave per substep
-#endif
 
 struct G4Args {
     const bf16* X;
@@ -186,15 +180,6 @@ template <int ACT, int S, int WV> __device__ __forceinline__ void gemm4w_body(co
         int t_;                                                                                                               \
         asm volatile("s_mul_i32 %1, %2, %3\n\tv_add_u32 %0, %1, %4" : "=v"(vo_), "=&s"(t_) : "s"(pitch_), "i"(rows_), "v"(lanepart_)); \
     } while (0)
-    // piece p (0 .. 15) of unit jj (0 / 1) of an operand into ring slot `slot`
-    auto stage_p = [&](auto isw_c, auto jj_c, int slot, auto p_c, __amdgpu_buffer_rsrc_t rs, int kbyte) __attribute__((always_inline)) {
-        constexpr bool isW = decltype(isw_c)::value != 0;
-        constexpr int jj = decltype(jj_c)::value, p = decltype(p_c)::value;
-        int vo;
-        if constexpr (isW) G4_VO(vo, 128 * jj + 32 * (p >> 2) + 4 * (p & 3), ldw2, voffWp[p & 1]);
-        else G4_VO(vo, 128 * jj + 8 * p, ldx2, voffXp[p & 1]);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + slot * G4_UNIT + p * 1024), 16, vo, kbyte, 0, 0);
-    };
     // the four pieces of a unit this wave moves when the waves share it: wave + 4 i (piece parity = wave parity; the wave's own
     // rows -- 8 wave (X), 4 wave (W) -- are part of the lane offset)
     auto stage_piece = [&](auto isw_c, auto jj_c, int slot, auto i_c, __amdgpu_buffer_rsrc_t rs, int kbyte) __attribute__((always_inline)) {
@@ -258,49 +243,13 @@ template <int ACT, int S, int WV> __device__ __forceinline__ void gemm4w_body(co
         asm volatile("v_xor_b32 %0, %1, %2" : "=v"(vX) : "s"((sx * G4_UNIT) | (((KS + 1) & 3) << 5)), "v"(lb));
         asm volatile("v_xor_b32 %0, %1, %2" : "=v"(vW) : "s"((sw * G4_UNIT) | (((KS + 1) & 3) << 5)), "v"(lb));
         __builtin_amdgcn_sched_barrier(0);
-        // MINE (mode 3 only): this wave requests all 16 pieces of the substep's unit, one per MFMA gap; the others none
-        auto gaps = [&](auto mine_c) __attribute__((always_inline)) {
-            constexpr int MINE = decltype(mine_c)::value;
+        {
+            // this wave's requests: gaps wave, wave + 4, wave + 8, wave + 12 (the timing experiments of profiles/r5_gemm4w_ablation.txt -- every
+            // wave in the same gaps, EXEC masks, branches, back-to-back requests, one wave per substep, and the wrong-result ablations --
+            // are in the history of this file: commit "gemm4w: four-wave persistent GEMM ...", not in the product source)
             auto dma = [&](auto g_c) __attribute__((always_inline)) {
                 constexpr int g = decltype(g_c)::value;
-                if constexpr ((G4_ABLATE & 1) != 0) {
-                } else if constexpr (G4_DMA_MODE == 0) {            // the waves take turns: wave w in gaps w, w + 4, w + 8, w + 12
-                    if constexpr ((g & 3) == wave) stage_piece(g4_c<isW>(), g4_c<jj>(), slot, g4_c<(g >> 2)>(), rs, kb);
-                } else if constexpr (G4_DMA_MODE == 1) {
-                    if constexpr ((g & 3) == 0) stage_piece(g4_c<isW>(), g4_c<jj>(), slot, g4_c<(g >> 2)>(), rs, kb);
-                } else if constexpr (G4_DMA_MODE == 2) {
-                    // every wave runs the request, with a live EXEC only in its own gaps (a VMEM instruction under EXEC = 0 does nothing)
-                    if constexpr ((g & 3) == 0) asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cselect_b64 exec, -1, 0" ::"s"(wave) : "scc");
-                    if constexpr ((g & 3) == 1) asm volatile("s_cmp_eq_u32 %0, 1\n\ts_cselect_b64 exec, -1, 0" ::"s"(wave) : "scc");
-                    if constexpr ((g & 3) == 2) asm volatile("s_cmp_eq_u32 %0, 2\n\ts_cselect_b64 exec, -1, 0" ::"s"(wave) : "scc");
-                    if constexpr ((g & 3) == 3) asm volatile("s_cmp_eq_u32 %0, 3\n\ts_cselect_b64 exec, -1, 0" ::"s"(wave) : "scc");
-                    stage_piece(g4_c<isW>(), g4_c<jj>(), slot, g4_c<(g >> 2)>(), rs, kb);
-                    asm volatile("s_mov_b64 exec, -1");
-                } else if constexpr (G4_DMA_MODE == 5) {            // the substep's four requests back to back in one gap
-                    if constexpr (g == 8) {
-                        stage_piece(g4_c<isW>(), g4_c<jj>(), slot, g4_c<0>(), rs, kb);
-                        stage_piece(g4_c<isW>(), g4_c<jj>(), slot, g4_c<1>(), rs, kb);
-                        stage_piece(g4_c<isW>(), g4_c<jj>(), slot, g4_c<2>(), rs, kb);
-                        stage_piece(g4_c<isW>(), g4_c<jj>(), slot, g4_c<3>(), rs, kb);
-                    }
-                } else if constexpr (G4_DMA_MODE == 6) {            // behind the fragment reads: gaps 8, 10, 12, 14
-                    if constexpr (g >= 8 && (g & 1) == 0) stage_piece(g4_c<isW>(), g4_c<jj>(), slot, g4_c<((g - 8) >> 1)>(), rs, kb);
-                } else if constexpr (G4_DMA_MODE == 7) {            // two and two: gaps 9 and 13
-                    if constexpr (g == 9 || g == 13) {
-                        stage_piece(g4_c<isW>(), g4_c<jj>(), slot, g4_c<(g == 9 ? 0 : 2)>(), rs, kb);
-                        stage_piece(g4_c<isW>(), g4_c<jj>(), slot, g4_c<(g == 9 ? 1 : 3)>(), rs, kb);
-                    }
-                } else if constexpr (G4_DMA_MODE == 4) {
-                    // pairs: waves 0, 1 request in gaps 0, 4, 8, 12, waves 2, 3 in gaps 2, 6, 10, 14
-                    if constexpr ((g & 1) == 0) {
-                        if constexpr ((g & 3) == 0) asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cselect_b64 exec, -1, 0" ::"s"(wr) : "scc");
-                        if constexpr ((g & 3) == 2) asm volatile("s_cmp_eq_u32 %0, 1\n\ts_cselect_b64 exec, -1, 0" ::"s"(wr) : "scc");
-                        stage_piece(g4_c<isW>(), g4_c<jj>(), slot, g4_c<(g >> 2)>(), rs, kb);
-                        asm volatile("s_mov_b64 exec, -1");
-                    }
-                } else if constexpr (G4_DMA_MODE == 3) {
-                    if constexpr (MINE) stage_p(g4_c<isW>(), g4_c<jj>(), slot, g4_c<g>(), rs, kb);
-                }
+                if constexpr ((g & 3) == wave) stage_piece(g4_c<isW>(), g4_c<jj>(), slot, g4_c<(g >> 2)>(), rs, kb);
             };
             auto gap = [&](auto g_c) __attribute__((always_inline)) {
                 constexpr int g = decltype(g_c)::value;
@@ -311,26 +260,18 @@ template <int ACT, int S, int WV> __device__ __forceinline__ void gemm4w_body(co
                     // may be overwritten) and the pieces of the next step's four units have landed.  Younger than those pieces: this
                     // substep's requests (4 per wave, or 16 of one wave) and its S stores of the previous tile.
                     dma(g_c);
-                    constexpr int young = (G4_DMA_MODE == 3 ? (MINE ? 16 : 0) : 4) + (SIDX >= 0 ? S : 0);
-                    if constexpr ((G4_ABLATE & 4) == 0) {
-                        if constexpr (young == 0) G4_WAIT(0);
-                        if constexpr (young == 4) G4_WAIT(4);
-                        if constexpr (young == 8) G4_WAIT(8);
-                        if constexpr (young == 12) G4_WAIT(12);
-                        if constexpr (young == 16) G4_WAIT(16);
-                        if constexpr (young == 20) G4_WAIT(20);
-                        if constexpr (young == 24) G4_WAIT(24);
-                    }
-                    if constexpr ((G4_ABLATE & 8) == 0) G4_BARRIER();
+                    constexpr int young = 4 + (SIDX >= 0 ? S : 0);
+                    if constexpr (young == 4) G4_WAIT(4);
+                    if constexpr (young == 8) G4_WAIT(8);
+                    if constexpr (young == 12) G4_WAIT(12);
+                    G4_BARRIER();
                 }
                 if constexpr (SIDX == 0 && KS == 0) acc[i][j] = g4_mma(fw[cur][i], fx[cur][j], vzero<f32x16>());
                 else acc[i][j] = g4_mma(fw[cur][i], fx[cur][j], acc[i][j]);
                 // fragments of the next substep, in the order its MFMAs want them: W0 X0 X1 X2 X3 W1 W2 W3
-                if constexpr ((G4_ABLATE & 2) == 0) {
-                    if constexpr (g == 0) fw[nxt][0] = *(const bf16x8*)(smem + vW);
-                    if constexpr (g >= 1 && g <= 4) fx[nxt][g - 1] = *(const bf16x8*)(smem + vX + (g - 1) * 4096);
-                    if constexpr (g >= 5 && g <= 7) fw[nxt][g - 4] = *(const bf16x8*)(smem + vW + (g - 4) * 4096);
-                }
+                if constexpr (g == 0) fw[nxt][0] = *(const bf16x8*)(smem + vW);
+                if constexpr (g >= 1 && g <= 4) fx[nxt][g - 1] = *(const bf16x8*)(smem + vX + (g - 1) * 4096);
+                if constexpr (g >= 5 && g <= 7) fw[nxt][g - 4] = *(const bf16x8*)(smem + vW + (g - 4) * 4096);
                 if constexpr (!bar) dma(g_c);
                 if constexpr (SIDX >= 0 && KS == 2) {
                     constexpr int every = 16 / S;
@@ -339,17 +280,14 @@ template <int ACT, int S, int WV> __device__ __forceinline__ void gemm4w_body(co
                         constexpr int qi = q >> 3, qr = q & 7;          // column block, (row block, half)
                         int vo;                                         // (asm volatile: else all 32 sums are hoisted out of the K loop)
                         G4_VO(vo, qr, rstep16, voffb[qi]);
-                        if constexpr ((G4_ABLATE & 16) == 0) __builtin_amdgcn_raw_buffer_store_b128(pk[q], dYp, vo, 0, G4_STORE_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(pk[q], dYp, vo, 0, G4_STORE_AUX);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
             gap(g4_c<0>()); gap(g4_c<1>()); gap(g4_c<2>()); gap(g4_c<3>()); gap(g4_c<4>()); gap(g4_c<5>()); gap(g4_c<6>()); gap(g4_c<7>());
             gap(g4_c<8>()); gap(g4_c<9>()); gap(g4_c<10>()); gap(g4_c<11>()); gap(g4_c<12>()); gap(g4_c<13>()); gap(g4_c<14>()); gap(g4_c<15>());
-        };
-        if constexpr (G4_DMA_MODE == 3) {
-            gaps(g4_c<(wave == KS ? 1 : 0)>());
-        } else gaps(g4_c<0>());
+        }
     };
     auto kstep = [&](auto sidx_c) __attribute__((always_inline)) {
         substep(g4_c<0>(), sidx_c);
