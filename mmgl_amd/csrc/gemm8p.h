@@ -20,6 +20,11 @@ bool gemm4w_supported(int M, int N, int K, int ldx, int ldw, int ldy);
 int launch_gemm4w(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, int M, int N, int K, float scale,
                   hipStream_t st);
 
+// the two wave groups of a CU on separate 128x256 half-tiles of one tile column, one group's epilogue beside the other's MFMAs (gemm8h.hip)
+bool gemm8h_supported(int M, int N, int K, int ldx, int ldw, int ldy);
+int launch_gemm8h(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, int M, int N, int K, float scale,
+                  hipStream_t st);
+
 // weight gradient on the same structure (gemm8p_tt.hip): Out[RB][RA] = scale * sum_m B[m][rb] A[m][ra], both operands k-major
 int gemm8p_tt_splits(int RA, int RB, int M);
 int launch_gemm8p_tt(const bf16* A, int lda, const bf16* B, int ldb, bf16* Out, float* part, int RA, int RB, int M, int nsplit, float scale,
