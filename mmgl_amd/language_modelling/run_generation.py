@@ -97,6 +97,13 @@ class Arguments:
     lora_alpha: float = _f(1, "lora scaling factor")
     lora_dropout: float = _f(0.0, "lora dropout rate")
 
+    # not in the reference: how its batch protocol is executed (train_loop)
+    fuse_grad_accumulation: Optional[bool] = _f(True, "run the grad_accumulation_steps micro-batches of one optimizer step as ONE "
+                                                "forward/backward pass over the concatenated samples (same samples, order, "
+                                                "optimizer steps and loss); False = one pass per micro-batch, literally")
+    fused_pass_tokens: int = _f(49152, "upper bound on samples x sequence length of one fused pass (memory); a group that "
+                                "exceeds it is cut into the fewest equal passes")
+
 
 # =============================================================================================== schedule / metrics
 class WarmupStepLR:
@@ -280,8 +287,126 @@ def _is_opt_self_attention(model):
     return isinstance(model, SelfAttentionModel) and hasattr(model.lm, "model") and hasattr(model.lm.model, "decoder")
 
 
+def _fusable(model, args, micro_batches):
+    """May the micro-batches of one optimizer step run as ONE forward / backward pass with the same result?  The reference's step is
+    sum_k mean_k(CE) / accum (:483-485); one pass over the concatenated samples computes a mean over ALL of them, which is the same
+    number exactly when every micro-batch scores the same number of positions: decoder-only labels without -100 (labels = input_ids,
+    data.py:331-333 -- every position counts) and equal micro-batch sizes (drop_last).  Encoder-decoder labels carry -100 at the pads
+    (unequal counts) and LayerDrop flips one coin per forward call (:581-584): those run the literal loop."""
+    if not getattr(args, "fuse_grad_accumulation", True) or not getattr(args, "decoder_only", False) or len(micro_batches) < 2:
+        return False
+    if any(getattr(m, "layerdrop", 0) and m.training for m in model.modules()):
+        return False
+    shapes = {k: tuple(v.shape) for k, v in micro_batches[0].items()}
+    for mb in micro_batches:
+        if {k: tuple(v.shape) for k, v in mb.items()} != shapes or bool((mb["labels"] == -100).any()):
+            return False
+    return True
+
+
+def _pass_sizes(n_micro, samples, tokens_per_sample, budget_tokens):
+    """Cut `n_micro` micro-batches into the fewest passes of at most `budget_tokens` tokens each, as even as possible (16 at a budget of
+    9 -> 8 + 8, not 9 + 7: the GEMM grids of both passes then fill the same number of tile rounds)."""
+    per = max(1, int(budget_tokens) // max(1, samples * tokens_per_sample)) if budget_tokens else n_micro
+    n_pass = -(-n_micro // per)
+    base, extra = divmod(n_micro, n_pass)
+    return [base + (1 if k < extra else 0) for k in range(n_pass)]
+
+
+_META_KEYS = ("attention_mask", "neighbor_pos_ids", "neighbor_attention_mask", "neighbor_images_pos_ids")
+
+
+class _GroupFeeder:
+    """The loader's micro-batches, grouped by optimizer step (`grad_accumulation_steps` consecutive ones; the epoch's last group may be
+    short, :485), each group already cut into passes and on the device.  `prefetch()` stages the NEXT group while the current one
+    computes: its host-to-device copies run on a side stream (the SDMA engines) under the backward pass instead of in front of the
+    next forward -- 3 MB of pixels per sample, ~8 ms per 64 samples on the critical path otherwise."""
+
+    def __init__(self, loader, model, args, device, accum):
+        self.it, self.model, self.args, self.device, self.accum = iter(loader), model, args, device, accum
+        self.i = 0                      # index of the next micro-batch
+        self.done = False
+        self.staged = None
+        self.stream = torch.cuda.Stream(device) if device.type == "cuda" else None
+
+    def _fetch(self):
+        if self.done:
+            return None
+        mbs, first = [], self.i
+        while True:
+            try:
+                mbs.append(next(self.it))
+            except StopIteration:
+                self.done = True
+                break
+            self.i += 1
+            if self.i % self.accum == 0:
+                break
+            if self.i == self.args.steps_per_epoch:
+                break
+        if self.i >= self.args.steps_per_epoch:
+            self.done = True
+        if not mbs:
+            return None
+        boundary = (self.i % self.accum == 0) or (self.i == self.args.steps_per_epoch)
+        n = len(mbs)
+        if _fusable(self.model, self.args, mbs):
+            B, T = mbs[0]["input_ids"].shape[:2]
+            sizes = _pass_sizes(n, B, T, getattr(self.args, "fused_pass_tokens", 49152))
+        else:
+            sizes = [1] * n
+        passes, k = [], 0
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else None
+        for sz in sizes:
+            part = mbs[k:k + sz]
+            k += sz
+            # host-side facts of the concatenated pass (small integer tensors only), read before the copy
+            small = {key: (torch.cat([mb[key] for mb in part]) if sz > 1 else part[0][key]) for key in _META_KEYS if key in part[0]}
+            extra = _host_meta(self.model, small) if "attention_mask" in small else {}
+            if ctx is not None:
+                with ctx:
+                    dev = [{key: v.to(self.device, non_blocking=True) for key, v in mb.items()} for mb in part]
+                    batch = dev[0] if sz == 1 else {key: torch.cat([d[key] for d in dev]) for key in dev[0]}
+            else:
+                dev = [{key: v.to(self.device) for key, v in mb.items()} for mb in part]
+                batch = dev[0] if sz == 1 else {key: torch.cat([d[key] for d in dev]) for key in dev[0]}
+            passes.append(dict(batch=batch, extra=extra, n_micro=sz, micro_size=part[0]["input_ids"].size(0)))
+        ready = None
+        if self.stream is not None:
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        return dict(passes=passes, n_micro=n, last_index=self.i - 1, first_index=first, boundary=boundary, ready=ready)
+
+    def prefetch(self):
+        if self.staged is None and not self.done:
+            self.staged = self._fetch()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        g, self.staged = (self.staged, None) if self.staged is not None else (self._fetch(), None)
+        if g is None:
+            raise StopIteration
+        if g["ready"] is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(g["ready"])
+            for p in g["passes"]:
+                for t in p["batch"].values():
+                    t.record_stream(cur)
+        return g
+
+
 def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, run=None):
-    """One epoch (reference :430-524).  `engine` = DataParallelEngine (replaces DDP + optimizer)."""
+    """One epoch (reference :430-524).  `engine` = DataParallelEngine (replaces DDP + optimizer).
+
+    The reference's protocol is `per_device_train_batch_size` x `grad_accumulation_steps` (2 x 16 in script/train_generation.sh:26-29,
+    4 x 4 by default): `accum` forward / backward passes of a few samples each per optimizer step.  Equal-size micro-batches with a
+    mean loss / accum ARE one batch of B * accum samples, and an MI355X holds it (288 GB): by default the group runs as ONE pass over
+    the concatenated samples -- same samples, same order, same optimizer / scheduler step count, the per-micro-batch summary-loss
+    meter kept per chunk (it ignores pads, so a mean of chunk means is not the mean over the pass) and the short last group still
+    scaled by 1 / accum (:485) -- cut only where `fused_pass_tokens` says memory demands.  `fuse_grad_accumulation=False` is the
+    literal loop (one pass per micro-batch); `_fusable` says when the literal loop runs regardless."""
     from . import utils
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -296,35 +421,43 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
     model.train()
     engine.zero_grad()
     history = []
+    sliced = args.decoder_only and (_takes_logits_slice(model) or _is_opt_self_attention(model))
+    feeder = _GroupFeeder(train_loader, model, args, device, accum)
     _sync(device)
     end = time.time()
-    for i, batch in enumerate(train_loader):
-        data_time.update(time.time() - end)
-        extra = _host_meta(model, batch)               # read off the batch while it is still in host memory
-        sliced = args.decoder_only and (_takes_logits_slice(model) or _is_opt_self_attention(model))
-        if sliced:                                     # the running summary loss below reads positions L_in .. T-2 only: the training
-            # step then never builds the [B, T, V] logits (explicit stop: SelfAttentionModel appends neighbor tokens after position T-1)
-            extra["logits_slice"] = slice(args.max_input_length, batch["input_ids"].shape[1] - 1)
-        batch = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
-        boundary = ((i + 1) % accum == 0) or (i == args.steps_per_epoch - 1)
-        engine.sync = boundary                         # gradients cross xGMI once per optimizer step
-        forward_start = time.time()
-        outputs = model(**batch, **extra)
-        _sync(device)
-        forward_time.update(time.time() - forward_start)
-        loss = outputs.loss
-        if args.decoder_only:
-            if sliced:
-                lg, lb = outputs.logits.detach(), batch["labels"][..., (args.max_input_length + 1):]
+    for group in feeder:
+        g = group["n_micro"]
+        data_time.update((time.time() - end) / g, g)
+        forward_s = 0.0
+        for pi, ps in enumerate(group["passes"]):
+            batch, extra, k = ps["batch"], dict(ps["extra"]), ps["n_micro"]
+            if sliced:                                 # the running summary loss below reads positions L_in .. T-2 only: the training
+                # step then never builds the [B, T, V] logits (explicit stop: SelfAttentionModel appends neighbor tokens after position T-1)
+                extra["logits_slice"] = slice(args.max_input_length, batch["input_ids"].shape[1] - 1)
+            engine.sync = group["boundary"] and pi == len(group["passes"]) - 1   # gradients cross xGMI once per optimizer step
+            forward_start = time.time()
+            outputs = model(**batch, **extra)
+            _sync(device)
+            forward_s += time.time() - forward_start
+            loss = outputs.loss
+            mb = ps["micro_size"]
+            if args.decoder_only:
+                if sliced:
+                    lg, lb = outputs.logits.detach(), batch["labels"][..., (args.max_input_length + 1):]
+                else:
+                    lg, lb = _summary_slices(args, outputs.logits.detach(), batch["labels"])
+                # one meter entry per MICRO-batch, as the literal loop records them (:473-480)
+                chunk = [_summary_cross_entropy(lg[c * mb:(c + 1) * mb], lb[c * mb:(c + 1) * mb], pad_id) for c in range(k)]
+                for v in (torch.stack([c.float().reshape(()) for c in chunk]).tolist() if k > 1 else [chunk[0].item()]):
+                    losses.update(v, mb)
             else:
-                lg, lb = _summary_slices(args, outputs.logits.detach(), batch["labels"])
-            summary_loss = _summary_cross_entropy(lg, lb, pad_id)
-            losses.update(summary_loss.item(), batch["input_ids"].size(0))
-        else:
-            losses.update(loss.item(), batch["input_ids"].size(0))
-        (loss / accum).backward()
-        engine.finish_backward()
-        if boundary:
+                losses.update(loss.item(), mb)
+            # the pass's loss is the mean over its k micro-batches' positions = (1 / k) * sum_k mean_k: times k / accum (:483)
+            (loss * (k / accum)).backward()
+            engine.finish_backward()
+        forward_time.update(forward_s / g, g)
+        lr = None
+        if group["boundary"]:
             # reference order (:486-494): optimizer.step() at the current lr, THEN scheduler.step() -- the warm-up starts at 0
             lr = scheduler.get_last_lr()[0] if scheduler is not None else None
             engine.step(lr)
@@ -332,23 +465,24 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
                 scheduler.step()
             # the reference clips only if grad_clip > 2, AFTER the step, i.e. to no effect (:490-493): nothing to do
             engine.zero_grad()
-            actual_step = (epoch * args.steps_per_epoch + i + 1) // accum
+        feeder.prefetch()                              # the next group's H2D copies run under this group's backward pass
+        _sync(device)
+        batch_time.update((time.time() - end) / g, g)
+        end = time.time()
+        if group["boundary"]:
+            actual_step = (epoch * args.steps_per_epoch + group["last_index"] + 1) // accum
             if actual_step == 1 or actual_step % args.print_freq == 0:
                 for m in (losses, batch_time, data_time, forward_time):
                     m.all_reduce()
                 ex_per_sec = (args.per_device_train_batch_size / max(batch_time.avg, 1e-9)) * world_size
-                history.append(dict(step=actual_step, loss=losses.avg, examples_per_sec=ex_per_sec, lr=lr))
+                history.append(dict(step=actual_step, loss=losses.avg, examples_per_sec=ex_per_sec, lr=lr,
+                                    passes=[p["n_micro"] for p in group["passes"]]))
                 if rank == 0:
-                    progress.display(i + 1)
+                    progress.display(group["last_index"] + 1)
                     print(f"  step {actual_step}: loss {losses.avg:.4f}  examples/sec {ex_per_sec:.2f}  "
                           f"data {data_time.avg:.3f}s  fwd {forward_time.avg:.3f}s  lr {lr}")
                 for m in (losses, batch_time, data_time, forward_time):
                     m.reset()
-        _sync(device)
-        batch_time.update(time.time() - end)
-        end = time.time()
-        if i == args.steps_per_epoch - 1:
-            break
     return history
 
 

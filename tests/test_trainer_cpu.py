@@ -125,3 +125,86 @@ def test_two_rank_gloo_trainer_keeps_ranks_in_sync(tmp_path):
     assert out["same"], "ranks diverged"
     assert len(out["hist"]) == 2 and out["exchange"] == 2 * out["numel"] * 4      # 2 optimizer steps, fp32 grads
     assert set(out["val"][0]) == {"loss", "bleu1", "bleu2", "bleu3", "bleu4", "cider"}
+
+
+# ------------------------------------------------------------------------------------------ the accumulation group as one pass
+class _ToyCausalLM(torch.nn.Module):
+    """decoder-only stand-in with the wrapper's call contract: model(**batch) -> .loss (mean CE over all shifted positions, the
+    reference's CrossEntropyLoss() at modelling_cross_attention.py:831-836) and .logits [B, T, V]"""
+
+    def __init__(self, vocab=23, d=16):
+        super().__init__()
+        self.emb = torch.nn.Embedding(vocab, d)
+        self.mix = torch.nn.Linear(d, d)
+        self.head = torch.nn.Linear(d, vocab)
+
+    def forward(self, input_ids, attention_mask, labels):
+        from types import SimpleNamespace
+        h = torch.tanh(self.mix(self.emb(input_ids))) * attention_mask.unsqueeze(-1)
+        logits = self.head(h)
+        loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.size(-1)), labels[:, 1:].reshape(-1))
+        return SimpleNamespace(loss=loss, logits=logits)
+
+
+def _toy_run(fuse, n_micro=11, accum=4, budget=49152, B=2, T=12):
+    from types import SimpleNamespace
+    from mmgl_amd.distributed import DataParallelEngine
+    from mmgl_amd.language_modelling.run_generation import train_loop
+    torch.manual_seed(5)
+    model = _ToyCausalLM().double()
+    g = torch.Generator().manual_seed(9)
+    batches = []
+    for _ in range(n_micro):
+        ids = torch.randint(2, 23, (B, T), generator=g)
+        am = torch.ones(B, T, dtype=torch.long)
+        for b in range(B):
+            n_pad = int(torch.randint(0, 4, (1,), generator=g))
+            if n_pad:
+                ids[b, -n_pad:] = 1
+                am[b, -n_pad:] = 0
+        batches.append(dict(input_ids=ids, attention_mask=am, labels=ids.clone()))
+    args = SimpleNamespace(steps_per_epoch=n_micro, grad_accumulation_steps=accum, decoder_only=True, max_input_length=T - 6, print_freq=1,
+                           per_device_train_batch_size=B, fuse_grad_accumulation=fuse, fused_pass_tokens=budget)
+    engine = DataParallelEngine(model, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01, fused=False)
+    sched = WarmupStepLR(1e-2, 2, 2, 0.5)
+    hist = train_loop(batches, model, None, engine, 0, sched, args)
+    return hist, torch.cat([p.detach().reshape(-1) for p in model.parameters()]), engine.step_count
+
+
+def test_fused_accumulation_equals_the_literal_loop_cpu():
+    """reference run_generation.py:462-494 executed as one pass per optimizer step: 11 micro-batches at accum 4 = groups of 4, 4 and
+    a short last group of 3 that is still scaled by 1 / accum (:485).  Same optimizer / scheduler step count, same lr sequence, same
+    per-micro-batch summary-loss meter, same parameters (fp64: to 1e-12) -- whole-group passes, and passes cut by the token budget."""
+    lit, p_lit, n_lit = _toy_run(False)
+    assert [h["passes"] for h in lit] == [[1, 1, 1, 1], [1, 1, 1, 1], [1, 1, 1]]
+    for budget, want in ((49152, [[4], [4], [3]]), (2 * 12 * 3, [[2, 2], [2, 2], [3]]), (2 * 12 * 2, [[2, 2], [2, 2], [2, 1]])):
+        fus, p_fus, n_fus = _toy_run(True, budget=budget)
+        assert [h["passes"] for h in fus] == want
+        assert n_fus == n_lit == 3
+        assert [h["lr"] for h in fus] == [h["lr"] for h in lit]
+        assert [h["step"] for h in fus] == [h["step"] for h in lit] == [1, 2, 2]       # (i + 1) // accum of the reference, short group incl.
+        for a, b in zip(fus, lit):
+            assert abs(a["loss"] - b["loss"]) < 1e-12
+        assert float((p_fus - p_lit).abs().max()) < 1e-12
+
+
+def test_fusion_is_declined_when_the_means_would_differ():
+    """labels with -100 (unequal numbers of scored positions per micro-batch) and LayerDrop models run the literal loop"""
+    from types import SimpleNamespace
+    from mmgl_amd.language_modelling.run_generation import _fusable, _pass_sizes
+    m = _ToyCausalLM()
+    ids = torch.randint(2, 23, (2, 8))
+    mb = dict(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids.clone())
+    args = SimpleNamespace(decoder_only=True)
+    assert _fusable(m, args, [mb, mb])
+    assert not _fusable(m, args, [mb])
+    assert not _fusable(m, SimpleNamespace(decoder_only=False), [mb, mb])
+    assert not _fusable(m, SimpleNamespace(decoder_only=True, fuse_grad_accumulation=False), [mb, mb])
+    bad = dict(mb, labels=mb["labels"].clone())
+    bad["labels"][0, 3] = -100
+    assert not _fusable(m, args, [mb, bad])
+    assert not _fusable(m, args, [mb, {k: v[:1] for k, v in mb.items()}])
+    m.layerdrop = 0.1
+    assert not _fusable(m, args, [mb, mb])
+    assert _pass_sizes(16, 2, 640, 49152) == [16] and _pass_sizes(16, 4, 2176, 49152) == [4, 4, 4, 4]
+    assert _pass_sizes(16, 2, 640, 9 * 1280) == [8, 8] and _pass_sizes(3, 64, 640, 49152) == [1, 1, 1]
