@@ -354,6 +354,8 @@ def main():
                     "tile schedule), reporting the `exchange` block: the device-side N>1 path on a 1-GPU box")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the `batch_sweep` block (the same step at per-GPU batches 4 / 16 / 32 / 64 up "
                     "to the run's own batch, outside the timed region)")
+    ap.add_argument("--no-protocol", action="store_true", help="skip `at_reference_protocol` (the reference's 4 x 4 and 2 x 16 batch protocols "
+                    "through the trainer's train_loop, fused and literal)")
     ap.add_argument("--ref-batch", type=int, default=4, help="also report the step at the reference's default per-device batch (Arguments default 4, run_generation.py:124-126); 0 = skip")
     args = ap.parse_args()
 
@@ -445,15 +447,16 @@ def main():
     last_meter = [0.0]
 
     # the trainer's step (reference run_generation.py:466-485; mmgl_amd train_loop): besides the token loss that is differentiated,
-    # the logits of the summary positions, their cross-entropy for the running meter, and its .item() -- a host sync -- every step
+    # the logits of the summary positions and their cross-entropy for the running meter.  The meter value stays a device scalar, as in
+    # train_loop (_Meters: resolved every print_freq optimizer steps, not per step): the host launches the next step while this one
+    # computes.  `at_reference_protocol` below goes through train_loop itself.
     lin = cfg["lin"]
     summary = slice(lin, T - 1)
 
     def step():
         out = model(**batch, logits_slice=summary)
         lg = out.logits.detach()
-        meter = _summary_cross_entropy(lg, batch["labels"][..., lin + 1:], 1).item()
-        last_meter[0] = meter
+        last_meter[0] = _summary_cross_entropy(lg, batch["labels"][..., lin + 1:], 1)
         out.loss.backward()
         engine.finish_backward()
         engine.step()
@@ -516,6 +519,47 @@ def main():
         t1 = float(t1.item())
         batch = keep
         return {"per_gpu_batch": bsz, "value": round(world * bsz * n / t1, 3), "unit": "samples/s", "ms_per_step": round(1e3 * t1 / n, 3), "steps": n}
+
+    # ---- the reference's own batch protocol THROUGH THE TRAINER (mmgl_amd train_loop, the function a user of the reference's
+    # settings runs): per_device_train_batch_size x grad_accumulation_steps = 4 x 4 (Arguments defaults, run_generation.py:124-126)
+    # and 2 x 16 (script/train_generation.sh:26-29), host micro-batches in pinned memory as the DataLoader hands them over (the H2D
+    # copies are inside the measurement), the group as ONE pass (default) beside the literal per-micro-batch loop
+    def at_protocol(per_device, accum, fuse, n_opt, warm_opt):
+        from types import SimpleNamespace
+        from mmgl_amd.language_modelling.run_generation import WarmupStepLR, train_loop
+        mbs = []
+        for i in range(accum * max(n_opt, warm_opt)):
+            hb, _ = synthetic_batch(per_device, cfg, seed=9000 + 100 * rank + i, device=torch.device("cpu"))
+            hb.pop("host_meta")
+            mbs.append({k: v.pin_memory() for k, v in hb.items()})
+        sched = WarmupStepLR(1e-4, 0, 1 << 30, 1.0)
+
+        def run(n_groups):
+            targs = SimpleNamespace(steps_per_epoch=accum * n_groups, grad_accumulation_steps=accum, decoder_only=True,
+                                    max_input_length=lin, print_freq=1 << 30, per_device_train_batch_size=per_device,
+                                    fuse_grad_accumulation=fuse, fused_pass_tokens=49152)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            train_loop(mbs[:accum * n_groups], model, None, engine, 0, sched, targs)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+        run(warm_opt)
+        t1 = torch.tensor([run(n_opt)], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+        t1 = float(t1.item())
+        return {"per_device_train_batch_size": per_device, "grad_accumulation_steps": accum, "one_pass_per_optimizer_step": fuse,
+                "value": round(world * per_device * accum * n_opt / t1, 3), "unit": "samples/s",
+                "ms_per_optimizer_step": round(1e3 * t1 / n_opt, 3), "optimizer_steps": n_opt}
+
+    protocol = None
+    if not args.no_protocol and cfg["kind"] in ("flamingo", "lora"):
+        protocol = {"through": "mmgl_amd.language_modelling.run_generation.train_loop (host micro-batches in pinned memory, H2D inside)"}
+        for per_device, accum in ((4, 4), (2, 16)):
+            protocol[f"{per_device}x{accum}"] = at_protocol(per_device, accum, True, 128 // (per_device * accum), 2)
+            protocol[f"{per_device}x{accum}_literal"] = at_protocol(per_device, accum, False, 64 // (per_device * accum), 1)
 
     ref_line = None
     if args.ref_batch and args.ref_batch < args.batch:
@@ -632,6 +676,8 @@ def main():
                                                   "peak_tflops": peak_tf, "scope": "GEMMs + attention core of the 4 gated cross-attention layers"}
             line["kernels_note"] = f"per C-ABI entry point over {table_steps} extra steps after the timed region"
             line["hip_path_ms_per_step"] = round(sum(s["ms_total"] for s in ks.values()) / table_steps, 2)
+        if protocol is not None:
+            line["at_reference_protocol"] = protocol
         if ref_line is not None:
             line["at_reference_batch"] = ref_line
         if sweep is not None:

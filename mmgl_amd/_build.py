@@ -24,21 +24,8 @@ CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-r
           "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
-# per-file flag changes: the four-wave GEMM keeps its 256 accumulators in the AGPR half of the register file (the VGPR form would
-# have to fit accumulators AND operands into 256 registers)
-DROP_FLAGS = {"gemm4w.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-
-
 def _cflags(src):
-    drop = DROP_FLAGS.get(os.path.basename(src), [])
-    out, i = [], 0
-    while i < len(CFLAGS):
-        if drop and CFLAGS[i:i + len(drop)] == drop:
-            i += len(drop)
-            continue
-        out.append(CFLAGS[i])
-        i += 1
-    return out
+    return list(CFLAGS)
 
 
 def _newer(src, dst, deps):

@@ -214,7 +214,10 @@ template <typename T> __global__ __launch_bounds__(256) void ag_bwd_dq_kernel(AG
                 if (pass == 0) {
                     delta[i] += wave_sum(dwd * p * ks);
                 } else {
-                    const float ds = (uniform ? 0.5f : 1.f) * p * (ks * dwd - delta[i]);
+                    // a row without any allowed key: every score IS finfo.min after the clamp and torch.max splits the gradient at the
+                    // tie -- except on keys masked TWICE (future and padded: finfo.min + finfo.min = -inf, the clamp constant wins outright)
+                    const float tie = (a.causal && s > t && !kvalid) ? 0.f : 0.5f;
+                    const float ds = (uniform ? tie : 1.f) * p * (ks * dwd - delta[i]);
                     for (int ss = 0; ss < AG_KC; ++ss) {
                         const float dss = __shfl(ds, ss);
                         acc[i][0] = fmaf(dss, Ks[ss * DP + lq], acc[i][0]);
@@ -288,7 +291,8 @@ template <typename T> __global__ __launch_bounds__(256) void ag_bwd_dkv_kernel(A
                     const float ks = hm * ag_keep_scale(a, thr, b, h, t, s);
                     const float dwd = ag_dot(Gs + tr * DP, Vs + lane * DP, D);
                     wd = p * ks;
-                    ds = (uniform ? 0.5f : 1.f) * p * (ks * dwd - delta);
+                    const float tie = (a.causal && s > t && !kvalid) ? 0.f : 0.5f;      // doubly-masked keys: see the dQ kernel
+                    ds = (uniform ? tie : 1.f) * p * (ks * dwd - delta);
                 }
             }
             Ws[tr * AG_KC + lane] = wd;

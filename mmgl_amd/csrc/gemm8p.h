@@ -15,16 +15,6 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
 // them has the same tile -> lane mapping as the one that wrote them); written by the act = 1 epilogue, applied by the plain one
 inline size_t gemm8p_bits_bytes(int M, int N) { return (size_t)cdiv(M, 256) * cdiv(N, 256) * 8192; }
 
-// four waves per CU, 128x128 wave tiles, the finished tile stored under the next tile's MFMAs (gemm4w.hip)
-bool gemm4w_supported(int M, int N, int K, int ldx, int ldw, int ldy);
-int launch_gemm4w(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, int M, int N, int K, float scale,
-                  hipStream_t st);
-
-// the two wave groups of a CU on separate 128x256 half-tiles of one tile column, one group's epilogue beside the other's MFMAs (gemm8h.hip)
-bool gemm8h_supported(int M, int N, int K, int ldx, int ldw, int ldy);
-int launch_gemm8h(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int ldy, const bf16* bias, int M, int N, int K, float scale,
-                  hipStream_t st);
-
 // weight gradient on the same structure (gemm8p_tt.hip): Out[RB][RA] = scale * sum_m B[m][rb] A[m][ra], both operands k-major
 int gemm8p_tt_splits(int RA, int RB, int M);
 int launch_gemm8p_tt(const bf16* A, int lda, const bf16* B, int ldb, bf16* Out, float* part, int RA, int RB, int M, int nsplit, float scale,

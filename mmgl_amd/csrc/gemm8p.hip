@@ -780,14 +780,6 @@ int launch_gemm8p(const bf16* X, int ldx, const bf16* W, int ldw, bf16* Y, int l
                                         "while mmgl_gemm_set_tile_counter is in effect)");
         a.sched = nullptr;                               // static schedule for this launch
     }
-    {
-        static const int use4w = getenv("MMGL_GEMM_4W") ? atoi(getenv("MMGL_GEMM_4W")) : 0;
-        static const int use8h = getenv("MMGL_GEMM_8H") ? atoi(getenv("MMGL_GEMM_8H")) : 0;
-        if (use8h && act == 0 && !resid && !zmask && !bits_out && !bits_in && !nsplit && !a.sched && gemm8h_supported(M, N, K, ldx, ldw, ldy))
-            return launch_gemm8h(X, ldx, W, ldw, Y, ldy, bias, M, N, K, scale, st);
-        if (use4w && act == 0 && !resid && !zmask && !bits_out && !bits_in && !nsplit && !a.sched && gemm4w_supported(M, N, K, ldx, ldw, ldy))
-            return launch_gemm4w(X, ldx, W, ldw, Y, ldy, bias, M, N, K, scale, st);
-    }
     if (direct > 0) {
         a.total = direct;
         const int grid = direct < n_cu ? direct : n_cu;

@@ -23,6 +23,7 @@
 // fp32 activations skip the t image (LDS budget) and gather it from the row image with scalar reads.
 #include "attn_common.h"
 #include <atomic>
+#include <mutex>
 
 namespace {
 
@@ -1184,32 +1185,34 @@ void fwd_geometry(int B, int H, int T, int tile_rows, int& rows_per_wg, int& nch
     nchunk = (T + rows - 1) / rows;
 }
 
-// hipFuncSetAttribute once per (kernel, device) and LDS size it has not been raised to yet: at the reference's batch the step is
-// launch-bound and this call sat in front of every cross-attention launch above 48 KiB
+// hipFuncSetAttribute ONCE per (kernel, device), to the hardware maximum (the attribute is a launch limit, not an allocation: the
+// launch's own dynamic size decides occupancy): at the reference's batch the step is launch-bound and this call sat in front of every
+// cross-attention launch above 48 KiB.  Lookup is lock-free; the first use of a (kernel, device) pair takes a mutex, so two threads
+// with different LDS sizes cannot leave the attribute below what the table says (it is never lowered: there is one value).
 template <typename K> int set_lds(K kern, size_t bytes) {
-    if (bytes > 160 * 1024) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "xattn: S*D needs %zu B of LDS (> 160 KiB)", bytes);
+    constexpr size_t kMaxLds = 160 * 1024;
+    if (bytes > kMaxLds) MMGL_FAIL(MMGL_ERR_UNSUPPORTED, "xattn: S*D needs %zu B of LDS (> 160 KiB)", bytes);
     if (bytes <= 48 * 1024) return MMGL_OK;
-    struct Slot { std::atomic<const void*> fn{nullptr}; std::atomic<int> dev{-1}; std::atomic<size_t> bytes{0}; };
-    static Slot slots[128];
+    struct Slot { std::atomic<const void*> fn{nullptr}; int dev = -1; };
+    static Slot slots[256];
+    static std::atomic<int> used{0};
+    static std::mutex mu;
     int dev = 0;
     (void)hipGetDevice(&dev);
     const void* fn = (const void*)kern;
-    Slot* mine = nullptr;
-    for (Slot& sl : slots) {
-        const void* f = sl.fn.load(std::memory_order_acquire);
-        if (f == fn && sl.dev.load(std::memory_order_relaxed) == dev) { mine = &sl; break; }
-        if (!f) {
-            const void* expect = nullptr;
-            if (sl.fn.compare_exchange_strong(expect, fn, std::memory_order_acq_rel)) { sl.dev.store(dev, std::memory_order_relaxed); mine = &sl; break; }
-            if (expect == fn && sl.dev.load(std::memory_order_relaxed) == dev) { mine = &sl; break; }
-        }
-    }
-    if (mine && mine->bytes.load(std::memory_order_acquire) >= bytes) return MMGL_OK;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    const int n = used.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i)
+        if (slots[i].fn.load(std::memory_order_relaxed) == fn && slots[i].dev == dev) return MMGL_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    const int n2 = used.load(std::memory_order_acquire);
+    for (int i = n; i < n2; ++i)
+        if (slots[i].fn.load(std::memory_order_relaxed) == fn && slots[i].dev == dev) return MMGL_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (e != hipSuccess) MMGL_FAIL(MMGL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    if (mine) {
-        size_t cur = mine->bytes.load(std::memory_order_relaxed);
-        while (cur < bytes && !mine->bytes.compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+    if (n2 < 256) {                                     // a full table only costs the call again next time
+        slots[n2].dev = dev;
+        slots[n2].fn.store(fn, std::memory_order_relaxed);
+        used.store(n2 + 1, std::memory_order_release);
     }
     return MMGL_OK;
 }

@@ -276,7 +276,7 @@ def _host_meta(model, batch):
     take them (`CrossAttentionModel.forward(host_meta=)`): the forward pass then never synchronises with the device."""
     from ..model.modelling_cross_attention import CrossAttentionModel, host_metadata
     if isinstance(model, CrossAttentionModel) and all(not v.is_cuda for v in batch.values()):
-        return {"host_meta": host_metadata(batch)}
+        return {"host_meta": host_metadata(batch, use_images=model.context in ("section_all", "all"))}
     return {}
 
 
@@ -397,6 +397,53 @@ class _GroupFeeder:
         return g
 
 
+class _Meters:
+    """The reference's four running meters (:447-450) without its per-micro-batch host synchronisation.  The reference calls
+    `summary_loss.item()` on every micro-batch (:480) and reads unsynchronised wall clocks; reading them right would cost a device
+    sync per step, and with syncs the host cannot launch the next pass while the current one computes -- at the reference's batch sizes
+    the launch stream is then the bottleneck.  Here the loss stays a device scalar and the times are HIP events; they are RESOLVED --
+    one synchronisation -- when somebody looks: every print_freq optimizer steps (:498-502) and at the end of the epoch.  The values
+    that reach the meters, and their order, are those of the per-step version."""
+
+    def __init__(self, device, utils):
+        self.cuda = device.type == "cuda"
+        self.batch_time = utils.AverageMeter("Time", ":6.3f")
+        self.data_time = utils.AverageMeter("Data", ":6.3f")
+        self.forward_time = utils.AverageMeter("Forward", ":6.3f")
+        self.losses = utils.AverageMeter("Loss", ":.4e")
+        self.pending = []
+
+    def all(self):
+        return (self.losses, self.batch_time, self.data_time, self.forward_time)
+
+    def mark(self):
+        if not self.cuda:
+            return time.time()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def span(self, meter, t0, t1, n):
+        self.pending.append((meter, t0, t1, n))
+
+    def loss(self, values, n):
+        """`values`: list of device (or host) scalars, one per micro-batch of `n` samples"""
+        self.pending.append((self.losses, values, None, n))
+
+    def resolve(self):
+        if self.cuda and self.pending:
+            torch.cuda.synchronize()
+        for meter, a, b, n in self.pending:
+            if meter is self.losses:
+                vals = torch.stack([v.float().reshape(()) for v in a]).tolist() if torch.is_tensor(a[0]) else a
+                for v in vals:
+                    meter.update(v, n)
+            else:
+                dt = a.elapsed_time(b) * 1e-3 if self.cuda else b - a
+                meter.update(dt / n, n)
+        self.pending = []
+
+
 def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, run=None):
     """One epoch (reference :430-524).  `engine` = DataParallelEngine (replaces DDP + optimizer).
 
@@ -406,16 +453,14 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
     the concatenated samples -- same samples, same order, same optimizer / scheduler step count, the per-micro-batch summary-loss
     meter kept per chunk (it ignores pads, so a mean of chunk means is not the mean over the pass) and the short last group still
     scaled by 1 / accum (:485) -- cut only where `fused_pass_tokens` says memory demands.  `fuse_grad_accumulation=False` is the
-    literal loop (one pass per micro-batch); `_fusable` says when the literal loop runs regardless."""
+    literal loop (one pass per micro-batch); `_fusable` says when the literal loop runs regardless.  The loop itself never waits for
+    the device (see _Meters): the next pass is launched while the current one computes."""
     from . import utils
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     device = _device_of(model)
-    batch_time = utils.AverageMeter("Time", ":6.3f")
-    data_time = utils.AverageMeter("Data", ":6.3f")
-    forward_time = utils.AverageMeter("Forward", ":6.3f")
-    losses = utils.AverageMeter("Loss", ":.4e")
-    progress = utils.ProgressMeter(args.steps_per_epoch, [batch_time, losses], prefix=f"Epoch: [{epoch}]")
+    mt = _Meters(device, utils)
+    progress = utils.ProgressMeter(args.steps_per_epoch, [mt.batch_time, mt.losses], prefix=f"Epoch: [{epoch}]")
     pad_id = tokenizer.pad_token_id if tokenizer is not None else 1
     accum = max(1, args.grad_accumulation_steps)
     model.train()
@@ -424,21 +469,19 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
     sliced = args.decoder_only and (_takes_logits_slice(model) or _is_opt_self_attention(model))
     feeder = _GroupFeeder(train_loader, model, args, device, accum)
     _sync(device)
-    end = time.time()
+    end, end_host = mt.mark(), time.time()
     for group in feeder:
         g = group["n_micro"]
-        data_time.update((time.time() - end) / g, g)
-        forward_s = 0.0
+        mt.data_time.update((time.time() - end_host) / g, g)      # host time spent waiting for the loader
         for pi, ps in enumerate(group["passes"]):
             batch, extra, k = ps["batch"], dict(ps["extra"]), ps["n_micro"]
             if sliced:                                 # the running summary loss below reads positions L_in .. T-2 only: the training
                 # step then never builds the [B, T, V] logits (explicit stop: SelfAttentionModel appends neighbor tokens after position T-1)
                 extra["logits_slice"] = slice(args.max_input_length, batch["input_ids"].shape[1] - 1)
             engine.sync = group["boundary"] and pi == len(group["passes"]) - 1   # gradients cross xGMI once per optimizer step
-            forward_start = time.time()
+            f0 = mt.mark()
             outputs = model(**batch, **extra)
-            _sync(device)
-            forward_s += time.time() - forward_start
+            mt.span(mt.forward_time, f0, mt.mark(), k)
             loss = outputs.loss
             mb = ps["micro_size"]
             if args.decoder_only:
@@ -447,15 +490,12 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
                 else:
                     lg, lb = _summary_slices(args, outputs.logits.detach(), batch["labels"])
                 # one meter entry per MICRO-batch, as the literal loop records them (:473-480)
-                chunk = [_summary_cross_entropy(lg[c * mb:(c + 1) * mb], lb[c * mb:(c + 1) * mb], pad_id) for c in range(k)]
-                for v in (torch.stack([c.float().reshape(()) for c in chunk]).tolist() if k > 1 else [chunk[0].item()]):
-                    losses.update(v, mb)
+                mt.loss([_summary_cross_entropy(lg[c * mb:(c + 1) * mb], lb[c * mb:(c + 1) * mb], pad_id) for c in range(k)], mb)
             else:
-                losses.update(loss.item(), mb)
+                mt.loss([loss.detach()], mb)
             # the pass's loss is the mean over its k micro-batches' positions = (1 / k) * sum_k mean_k: times k / accum (:483)
             (loss * (k / accum)).backward()
             engine.finish_backward()
-        forward_time.update(forward_s / g, g)
         lr = None
         if group["boundary"]:
             # reference order (:486-494): optimizer.step() at the current lr, THEN scheduler.step() -- the warm-up starts at 0
@@ -465,24 +505,28 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
                 scheduler.step()
             # the reference clips only if grad_clip > 2, AFTER the step, i.e. to no effect (:490-493): nothing to do
             engine.zero_grad()
-        feeder.prefetch()                              # the next group's H2D copies run under this group's backward pass
-        _sync(device)
-        batch_time.update((time.time() - end) / g, g)
-        end = time.time()
+        now = mt.mark()
+        mt.span(mt.batch_time, end, now, g)
+        end, end_host = now, time.time()
+        feeder.prefetch()                              # the next group's H2D copies run under this group's passes
         if group["boundary"]:
             actual_step = (epoch * args.steps_per_epoch + group["last_index"] + 1) // accum
             if actual_step == 1 or actual_step % args.print_freq == 0:
-                for m in (losses, batch_time, data_time, forward_time):
+                mt.resolve()
+                for m in mt.all():
                     m.all_reduce()
-                ex_per_sec = (args.per_device_train_batch_size / max(batch_time.avg, 1e-9)) * world_size
-                history.append(dict(step=actual_step, loss=losses.avg, examples_per_sec=ex_per_sec, lr=lr,
+                ex_per_sec = (args.per_device_train_batch_size / max(mt.batch_time.avg, 1e-9)) * world_size
+                history.append(dict(step=actual_step, loss=mt.losses.avg, examples_per_sec=ex_per_sec, lr=lr,
                                     passes=[p["n_micro"] for p in group["passes"]]))
                 if rank == 0:
                     progress.display(group["last_index"] + 1)
-                    print(f"  step {actual_step}: loss {losses.avg:.4f}  examples/sec {ex_per_sec:.2f}  "
-                          f"data {data_time.avg:.3f}s  fwd {forward_time.avg:.3f}s  lr {lr}")
-                for m in (losses, batch_time, data_time, forward_time):
+                    print(f"  step {actual_step}: loss {mt.losses.avg:.4f}  examples/sec {ex_per_sec:.2f}  "
+                          f"data {mt.data_time.avg:.3f}s  fwd {mt.forward_time.avg:.3f}s  lr {lr}")
+                for m in mt.all():
                     m.reset()
+                end, end_host = mt.mark(), time.time()
+    mt.resolve()
+    _sync(device)
     return history
 
 

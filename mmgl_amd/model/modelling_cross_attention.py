@@ -758,11 +758,14 @@ def _conv_patch_embed_as_gemm(module: nn.Module):
             m.__class__ = _PatchEmbedLinear
 
 
-def _valid_rows_host(pos_ids_cpu):
+def _valid_rows_host(pos_ids_cpu, sample_has_key=None):
     """Indices (CPU LongTensor) of neighbor slots with pos_id > 0, or None when every slot is valid OR some sample has no valid
-    slot at all (then padded slots DO matter: a fully-masked sample attends uniformly over all its keys)."""
+    key at all (then padded slots DO matter: a fully-masked sample attends uniformly over all its keys).  `sample_has_key` [B] bool:
+    whether each sample has a valid slot in ANY modality (a sample without images still has its page-info text neighbor, reference
+    data.py:355-361 -- its padded image slots get probability exactly 0); default: judged on this modality alone."""
     valid = pos_ids_cpu > 0
-    if bool(valid.all()) or not bool(valid.any(dim=1).all()):
+    has_key = valid.any(dim=1) if sample_has_key is None else sample_has_key
+    if bool(valid.all()) or not bool(has_key.all()):
         return None
     return valid.reshape(-1).nonzero().squeeze(1)
 
@@ -773,15 +776,20 @@ def _valid_rows(pos_ids):
     return None if rows is None else rows.to(pos_ids.device)
 
 
-def host_metadata(batch):
+def host_metadata(batch, use_images=True):
     """What the forward pass needs to know on the HOST, computed from a batch that is still in host memory (the collate
     output, before the H2D copy): which neighbor slots are real (reference data.py:444-454 pads with pos_id 0), how long every
     real neighbor text is (the packing of the padding-free encoder), and that every sequence starts with a valid token.
     Passing it as `host_meta=` removes every device->host synchronisation from the training step."""
     meta = {"first_key_valid": bool((batch["attention_mask"][:, 0] != 0).all())}
     npos = batch.get("neighbor_pos_ids")
+    ipos = batch.get("neighbor_images_pos_ids") if use_images else None      # context text_only: image slots are not keys
+    has_key = None                                     # per sample: a valid neighbor slot in any modality
+    for pos in (npos, ipos):
+        if pos is not None:
+            has_key = (pos.cpu() > 0).any(dim=1) if has_key is None else has_key | (pos.cpu() > 0).any(dim=1)
     if npos is not None and "neighbor_attention_mask" in batch:
-        rows = _valid_rows_host(npos.cpu())
+        rows = _valid_rows_host(npos.cpu(), has_key)
         am = batch["neighbor_attention_mask"].cpu()
         am = am.reshape(-1, am.shape[-1]) != 0
         if rows is not None:
@@ -789,9 +797,8 @@ def host_metadata(batch):
         meta["text_rows"] = rows
         meta["text_lens"] = am.sum(1).to(torch.int32)
         meta["text_first_valid"] = bool(am[:, 0].all()) if am.numel() else True
-    ipos = batch.get("neighbor_images_pos_ids")
     if ipos is not None:
-        meta["image_rows"] = _valid_rows_host(ipos.cpu())
+        meta["image_rows"] = _valid_rows_host(ipos.cpu(), has_key)
     return meta
 
 

@@ -106,7 +106,8 @@ class _AttnGeneral(torch.autograd.Function):
 def attn_general(q, k, v, key_valid, num_heads, causal=False, head_mask=None, p_drop=0.0, training=False, seed=None, output_attentions=False):
     """The attention core with the options the fused kernels leave out (reference model/modelling_cross_attention.py:206-271):
     `head_mask` [H] scales the probabilities of each head (:237-244), `output_attentions` also returns them as [B,H,T,S] -- head-masked,
-    before dropout, not differentiable (:246-254) --, `p_drop` drops probabilities in training (:256; counter hash of (seed, index),
+    before dropout (:246-254); the returned tensor is DETACHED (the reference keeps it in the graph, ":248 make sure that attn_weights
+    keeps its gradient": differentiating through the returned probabilities is not supported here and autograd will say so) --, `p_drop` drops probabilities in training (:256; counter hash of (seed, index),
     regenerated in backward).  q [B,T,d] is already scaled; causal = the decoder's self-attention (S == T).  Returns (out, probs | None)."""
     if q.dim() != 3 or k.shape != v.shape or k.dim() != 3 or q.shape[0] != k.shape[0] or q.shape[2] != k.shape[2]:
         raise ValueError(f"attn_general: incompatible shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
@@ -116,6 +117,11 @@ def attn_general(q, k, v, key_valid, num_heads, causal=False, head_mask=None, p_
         raise ValueError(f"Attention mask should be of size {tuple(k.shape[:2])}, but is {tuple(key_valid.shape)}")
     if head_mask is not None and tuple(head_mask.shape) != (num_heads,):
         raise ValueError(f"Head mask for a single layer should be of size {(num_heads,)}, but is {tuple(head_mask.shape)}")
+    if head_mask is not None and head_mask.requires_grad and torch.is_grad_enabled():
+        # the reference's head mask is an ordinary multiplicand (:243): a head-importance / pruning workflow differentiates through it.
+        # This kernel treats it as a constant -- refuse rather than hand back a silent zero gradient
+        raise NotImplementedError("attn_general: head_mask.requires_grad is not supported (the kernel computes no gradient for the head "
+                                  "mask); detach it, or differentiate a per-head scale applied outside the attention core")
     if key_valid.dtype != torch.uint8:
         key_valid = key_valid.to(torch.uint8)
     p = float(p_drop) if training else 0.0

@@ -65,6 +65,44 @@ def test_attn_general_matches_oracle(shape, dtype):
     assert_close(vd.grad.float(), vr.grad, tol, "dv")
 
 
+def test_left_padded_causal_rows_without_an_allowed_key():
+    """MPTAttention called directly with LEFT padding (the decoder itself asserts key 0 valid): the first rows of a sample see only padded
+    keys -> every score is finfo.min after the clamp (uniform probabilities over all S keys), and torch.max splits the gradient at the
+    tie 0.5 / 0.5 -- except on keys masked twice (future AND padded: finfo.min + finfo.min = -inf, the clamp constant wins outright).
+    Reference model/modelling_cross_attention.py:51-79, 226-228; the oracle's torch.maximum reproduces both cases through autograd."""
+    from mmgl_amd import ops
+    B, H, T, D = 2, 2, 70, 16
+    g = torch.Generator().manual_seed(77)
+    q, k, v, w = (torch.randn(B, T, H * D, generator=g) * s for s in (0.4, 1.0, 1.0, 1.0))
+    valid = torch.ones(B, T, dtype=torch.bool)
+    valid[0, :5] = False                       # rows 0..4 of sample 0 have no allowed key
+    valid[0, 40:43] = False                    # padded keys in the future of those rows: doubly masked
+    valid[1, 0] = False
+    valid[1, 66:] = False
+    qd, kd, vd = (x.cuda().requires_grad_() for x in (q, k, v))
+    out, _ = ops.attn_general(qd, kd, vd, valid.cuda(), H, causal=True)
+    (out * w.cuda()).sum().backward()
+    qr, kr, vr = (x.clone().requires_grad_() for x in (q, k, v))
+    ro = lm_ref.attention_core(qr, kr, vr, lm_ref.decoder_self_mask(valid, torch.float32), H)
+    (ro * w).sum().backward()
+    assert_close(out, ro, 1e-4, "out")
+    assert_close(qd.grad, qr.grad, 1e-4, "dq")
+    assert_close(kd.grad, kr.grad, 1e-4, "dk")
+    assert_close(vd.grad, vr.grad, 1e-4, "dv")
+    # the doubly-masked keys receive gradient only from rows that do not see them as a tie: compare them on their own
+    assert_close(kd.grad[0, 40:43], kr.grad[0, 40:43], 1e-4, "dk of the doubly-masked keys")
+
+
+def test_head_mask_with_requires_grad_is_refused():
+    from mmgl_amd import ops
+    q, k, v, valid, _ = _mk(1, 2, 8, 8, 16, False, 1)
+    hm = torch.ones(2, device="cuda", requires_grad=True)
+    with pytest.raises(NotImplementedError, match="head_mask"):
+        ops.attn_general(q.cuda(), k.cuda(), v.cuda(), valid.cuda(), 2, head_mask=hm)
+    with torch.no_grad():
+        ops.attn_general(q.cuda(), k.cuda(), v.cuda(), valid.cuda(), 2, head_mask=hm)
+
+
 def test_attn_dropout_mask_statistics_and_determinism():
     from mmgl_amd import ops
     B, H, T, S, p = 4, 8, 256, 64, 0.1

@@ -301,11 +301,14 @@ def test_full_size_step_matches_cpu_oracle(name, nsamp):
         # max-norm 5e-2, rms 1e-2: a ReLU (fc1) whose pre-activation sits within round-off of zero is on in one implementation and
         # off in the other -- a whole term of a weight-gradient element appears or not (measured round 5: 1.9e-2 max-norm at
         # neighbor_layers.0.fc1.weight with everything else at 1e-3 .. 1e-4); the rms error does not see single flips
-        e_max = assert_close(g.float().cpu(), sd[k].grad, 5e-2, f"fp32 d {k}")
+        # Only the parameters BEHIND that ReLU get the wide bound; everything else (projections, biases, norms, embeddings) is held to 1e-2.
+        relu_side = k.endswith(("fc1.weight", "fc1.bias", "fc2.weight"))
+        e_max = assert_close(g.float().cpu(), sd[k].grad, 5e-2 if relu_side else 1e-2, f"fp32 d {k}")
         ref = sd[k].grad.double()
         e_rms = float((g.double().cpu() - ref).pow(2).mean().sqrt() / max(float(ref.pow(2).mean().sqrt()), 1e-9))
         assert e_rms <= 2e-2 or float(ref.abs().max()) < 1e-6, (k, e_rms)
-        e_el = elementwise_err(g.float().cpu(), sd[k].grad, floor_frac=1e-2)      # reported, not asserted (see above)
+        e_el = elementwise_err(g.float().cpu(), sd[k].grad, floor_frac=1e-2)
+        assert relu_side or e_el <= 0.25, (k, e_el)     # element-wise, floor = 1e-2 of the largest gradient (see above); ReLU side: reported
         if e_max > worst[0]:
             worst = (e_max, e_el, k)
     print(f"   fp32 gradients of all {len(trainable)} trainable parameters vs CPU oracle: worst max-norm rel err {worst[0]:.2e} "
