@@ -601,7 +601,8 @@ def main():
         engine.sync = True
         step_s = dt / args.steps
         exposed = max(0.0, step_s - nosync_s)
-        exchange = {"rccl_ranks": int(ones.item()), "backend": backend, "forced": forced, "buckets": len(engine.buckets),
+        exchange = {"rccl_ranks": int(ones.item()), "backend": backend, "forced": forced, "buckets": len(engine.buckets), "bucket_mb": round(engine.bucket_mb, 2),
+                    "first_bucket_fraction_of_gradient": round((engine.buckets[0]["end"] - engine.buckets[0]["start"]) / engine.numel, 4),
                     "exchange_bytes_per_step_per_gpu": int(bytes_per_step),
                     "wire_bytes_per_step_per_gpu": int(2 * (world - 1) / world * bytes_per_step),
                     "allreduce_ms_alone": round(ar_s * 1e3, 3), "step_ms_without_exchange": round(nosync_s * 1e3, 3),

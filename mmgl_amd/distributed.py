@@ -8,12 +8,13 @@ xGMI-shaped design:
     buffer, laid out in expected grad-ready order (last cross-attention layer first), so autograd accumulates
     straight into communication-ready memory and the optimizer is a single fused HIP kernel over the flat buffers
     (mmgl_adamw_step) instead of ~100 small per-tensor launches;
-  * the flat gradient is cut into few LARGE contiguous buckets (default 256 MiB; xGMI is point-to-point, 7 links x
-    ~153 GB/s per GPU, so RCCL's ring/direct algorithms want big messages, not DDP's 25 MiB NVSwitch-era buckets);
+  * the flat gradient is cut into few LARGE contiguous buckets (default: an eighth of the gradient volume, 1..256 MiB -- 54 MB at
+    config 3; xGMI is point-to-point, 7 links x ~153 GB/s per GPU, so RCCL's ring/direct algorithms want big messages, not DDP's
+    25 MiB NVSwitch-era buckets, but the FIRST bucket must close early in backward for the exchange to hide behind the rest);
     a bucket's all-reduce is launched from a post-accumulate-grad hook the moment its last gradient lands, so the
     exchange overlaps the rest of backward on RCCL's own stream.  Only the LAST-ready bucket has nothing left to hide
     behind, so the tail of the flat buffer (the lowest gated layer and the neighbor projections) is cut off as its own
-    small bucket (`tail_mb`, default 32 MiB: ~1 ms on one xGMI link at 2 GPUs instead of ~5 ms for a full bucket);
+    small bucket (`tail_mb`, default min(32 MiB, bucket): ~1 ms on one xGMI link at 2 GPUs);
   * gradients are exchanged ONCE PER OPTIMIZER STEP (set `sync=False` on the non-final micro-batches): the reference
     all-reduces on every micro-batch because it never uses no_sync() (run_generation.py:484-485); the sum is the same
     up to summation order, the wire traffic is grad_accumulation_steps x smaller;
@@ -41,7 +42,7 @@ def _grad_ready_order(named_params):
 
 class DataParallelEngine:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.95), eps: float = 1e-8,
-                 weight_decay: float = 0.01, bucket_mb: float = 256, tail_mb: float = 32, process_group=None, master_weights: Optional[bool] = None,
+                 weight_decay: float = 0.01, bucket_mb: Optional[float] = None, tail_mb: Optional[float] = None, process_group=None, master_weights: Optional[bool] = None,
                  fused: Optional[bool] = None, broadcast: bool = True, optimizer: str = "adamw", force_exchange: Optional[bool] = None):
         import os
         self.model = model
@@ -105,7 +106,18 @@ class DataParallelEngine:
             raise ValueError(f"unknown optimizer {optimizer!r}")
 
         # ---- buckets = contiguous ranges of the flat gradient, closed in grad-ready order
-        cap = max(1, bucket_mb * (1 << 20) // self.flat_grad.element_size())
+        # bucket size from the gradient volume (bucket_mb=None): an eighth of the flat gradient, at most 256 MiB, at least 1 MiB.  A fixed
+        # 256 MiB (rounds 1-5) held config 3's first all-reduce back until ~60 % of the backward pass (433 MB of bf16 gradients = 1.7
+        # buckets); an eighth closes the first bucket inside the LAST gated layer's backward (a gated layer is ~23 % of the trainable
+        # set at every config) and keeps >= 8 collectives in flight behind the rest of backward, each still tens of MB at OPT-1.3B
+        # (xGMI is point-to-point: ring steps want MBs, not DDP's 25 MiB/8-way split -- 54 MB buckets are 6.8 MB per ring step at 8 GPUs)
+        total_mb = self.numel * self.flat_grad.element_size() / (1 << 20)
+        if bucket_mb is None:
+            bucket_mb = min(256.0, max(1.0, total_mb / 8))
+        if tail_mb is None:
+            tail_mb = min(32.0, bucket_mb)
+        self.bucket_mb, self.tail_mb = bucket_mb, tail_mb
+        cap = max(1, int(bucket_mb * (1 << 20)) // self.flat_grad.element_size())
         self.buckets: List[Dict] = []
         start, members = 0, []
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):

@@ -101,6 +101,8 @@ class Arguments:
     fuse_grad_accumulation: Optional[bool] = _f(True, "run the grad_accumulation_steps micro-batches of one optimizer step as ONE "
                                                 "forward/backward pass over the concatenated samples (same samples, order, "
                                                 "optimizer steps and loss); False = one pass per micro-batch, literally")
+    fuse_eval_batches: Optional[bool] = _f(True, "evaluate_loop: several validation batches share one forward pass (bounded by "
+                                           "fused_pass_tokens); meters, gathers and caption order stay per batch")
     fused_pass_tokens: int = _f(49152, "upper bound on samples x sequence length of one fused pass (memory); a group that "
                                 "exceeds it is cut into the fewest equal passes")
 
@@ -530,9 +532,35 @@ def train_loop(train_loader, model, tokenizer, engine, epoch, scheduler, args, r
     return history
 
 
+def _eval_groups(loader, args, limit):
+    """Consecutive validation batches, `k` at a time (k * B * T <= fused_pass_tokens; samples are independent in eval mode, so one
+    forward over k batches is k forwards) -- at per_device_val_batch_size 2 (script/train_generation.sh) a forward per batch leaves
+    the GPU waiting for the launch stream."""
+    group, n = [], 0
+    for batch in loader:
+        n += 1
+        if group and any(tuple(v.shape) != tuple(group[0][key].shape) for key, v in batch.items()):
+            yield group
+            group = []
+        group.append(batch)
+        B, T = batch["input_ids"].shape[:2]
+        k = 1                                           # encoder-decoder: the wrapper's own loss is the meter (:577-579) -> one batch per pass
+        if getattr(args, "fuse_eval_batches", True) and args.decoder_only:
+            k = max(1, int(getattr(args, "fused_pass_tokens", 49152)) // max(1, B * T))
+        if len(group) >= k:
+            yield group
+            group = []
+        if n == limit:
+            break
+    if group:
+        yield group
+
+
 def evaluate_loop(val_loader, model, tokenizer, epoch, args, run=None, prefix="val"):
     """Teacher-forced evaluation (reference :527-703): argmax tokens on the summary span, all-gathered, decoded,
-    truncated at the first '.', scored with BLEU-1..4 and CIDEr.  Returns BLEU-4 (the model-selection metric, :703)."""
+    truncated at the first '.', scored with BLEU-1..4 and CIDEr.  Returns BLEU-4 (the model-selection metric, :703).
+    Several validation batches share one forward pass (_eval_groups); meters, gathers and caption order are per batch, as in the
+    reference.  `evaluate_loop.last` also carries `samples_per_sec` (this rank's samples / wall time of the loop)."""
     from . import utils
     from ..wikiweb2m.cider import Cider
     world_size = dist.get_world_size() if dist.is_initialized() else 1
@@ -544,19 +572,34 @@ def evaluate_loop(val_loader, model, tokenizer, epoch, args, run=None, prefix="v
     pad_id = tokenizer.pad_token_id
     model.eval()
     gen_caps, gt_caps = [], []
+    sliced = args.decoder_only and (_takes_logits_slice(model) or _is_opt_self_attention(model))
+    n_samples, seen = 0, 0
+    _sync(device)
+    t_loop = time.time()
     with torch.no_grad():
         end = time.time()
-        for i, batch in enumerate(val_loader):
-            extra = _host_meta(model, batch)
-            batch = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
+        for group in _eval_groups(val_loader, args, args.val_steps_per_epoch):
+            k, mb = len(group), group[0]["input_ids"].size(0)
+            small = {key: (torch.cat([b[key] for b in group]) if k > 1 else group[0][key]) for key in _META_KEYS if key in group[0]}
+            extra = _host_meta(model, small) if "attention_mask" in small else {}
+            dev = [{key: v.to(device, non_blocking=True) for key, v in b.items()} for b in group]
+            batch = dev[0] if k == 1 else {key: torch.cat([d[key] for d in dev]) for key in dev[0]}
+            if sliced:                                 # only the summary positions' logits are read below (:584-591)
+                extra["logits_slice"] = slice(args.max_input_length, batch["input_ids"].shape[1] - 1)
             outputs = model(**batch, **extra)
             logits = outputs.logits
             if args.decoder_only:
-                logits, labels = _summary_slices(args, logits, batch["labels"])
-                loss = nn.functional.cross_entropy(logits.reshape(-1, logits.size(-1)).float(), labels.reshape(-1), ignore_index=pad_id)
+                if sliced:
+                    labels = batch["labels"][..., (args.max_input_length + 1):]
+                else:
+                    logits, labels = _summary_slices(args, logits, batch["labels"])
+                chunk = [_summary_cross_entropy(logits[c * mb:(c + 1) * mb], labels[c * mb:(c + 1) * mb], pad_id) for c in range(k)]
+                chunk = torch.stack([c.float().reshape(()) for c in chunk]).tolist()
             else:
-                labels, loss = batch["labels"], outputs.loss
-            losses.update(loss.item(), batch["input_ids"].size(0))
+                labels = batch["labels"]
+                chunk = [outputs.loss.item()]
+            for v in chunk:
+                losses.update(v, mb)
             if prefix == "test" and hasattr(model, "generate"):
                 generated_ids = model.generate(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], max_new_tokens=32)
             else:
@@ -568,7 +611,9 @@ def evaluate_loop(val_loader, model, tokenizer, epoch, args, run=None, prefix="v
                 tl = [torch.zeros_like(labels) for _ in range(world_size)]
                 dist.all_gather(gl, generated_ids)
                 dist.all_gather(tl, labels)
-                generated_ids, labels = torch.cat(gl), torch.cat(tl)
+                # the reference gathers per batch (:608-616): batch c of every rank, rank-major, then batch c + 1
+                generated_ids = torch.cat([g[c * mb:(c + 1) * mb] for c in range(k) for g in gl])
+                labels = torch.cat([t[c * mb:(c + 1) * mb] for c in range(k) for t in tl])
             if not args.decoder_only:
                 labels = labels.masked_fill(labels == -100, pad_id)
             preds = tokenizer.batch_decode(generated_ids, skip_special_tokens=True)
@@ -577,12 +622,14 @@ def evaluate_loop(val_loader, model, tokenizer, epoch, args, run=None, prefix="v
                 stop = p.find(".")
                 gen_caps.append(p[:stop] if stop > 5 else p)
                 gt_caps.append([g])
-            batch_time.update(time.time() - end)
+            n_samples += k * mb
+            batch_time.update((time.time() - end) / k, k)
             end = time.time()
-            if i % args.print_freq == 0 and rank == 0:
-                progress.display(i + 1)
-            if i == args.val_steps_per_epoch - 1:
-                break
+            if any((seen + c) % args.print_freq == 0 for c in range(k)) and rank == 0:
+                progress.display(seen + k)
+            seen += k
+    _sync(device)
+    t_loop = time.time() - t_loop
     bleu = [corpus_bleu(gen_caps, gt_caps, n) for n in (1, 2, 3, 4)]
     cands = {idx: [p] for idx, p in enumerate(gen_caps)}
     refs = {idx: g for idx, g in enumerate(gt_caps)}
@@ -596,6 +643,7 @@ def evaluate_loop(val_loader, model, tokenizer, epoch, args, run=None, prefix="v
     if rank == 0:
         print(f"[{prefix}] epoch {epoch}: " + "  ".join(f"{k} {v:.4f}" for k, v in meters.items()) + f"  ({len(gen_caps)} captions)")
     evaluate_loop.last = meters
+    evaluate_loop.samples_per_sec = n_samples / max(t_loop, 1e-9)
     return meters["bleu4"]
 
 

@@ -626,16 +626,15 @@ def lm_head_loss_and_logits(module, lm_head, hidden, next_labels, return_logits=
     """(loss, logits) of a causal-LM head (reference :826-836).  Default = the reference's contract: full [B, T, V] logits and a
     separate cross-entropy.  A caller that does not need them (the trainer, the benchmark) says so -- `return_logits=False`, or
     `logits_slice` (a slice along T: the logits of just those positions, without gradient: what the trainer's running summary
-    loss reads, run_generation.py:473-480 looks at positions max_input_length..T-1 only) -- and a TRAINING step with a frozen head
-    (every peft mode of the reference: the head is tied to the frozen embedding) then runs ops.lm_head_cross_entropy: lm_head and
+    loss reads, run_generation.py:473-480 looks at positions max_input_length..T-1 only) -- and a step with a frozen head (training or
+    evaluation; every peft mode of the reference: the head is tied to the frozen embedding) then runs ops.lm_head_cross_entropy: lm_head and
     the token cross-entropy fused, the [B, T, V] logits and their gradient (4.1 GB each at B=64) never built.  The fused kernel
     needs the head's dimensions aligned to its 16-byte lanes; otherwise the unfused pair (which pads) runs."""
     frozen = type(lm_head) is nn.Linear and not lm_head.weight.requires_grad and lm_head.bias is None
     lanes = 16 // hidden.element_size()
     aligned = lm_head.weight.shape[0] % lanes == 0 and lm_head.weight.shape[1] % lanes == 0
     opted_out = return_logits is False or (return_logits is None and logits_slice is not None)
-    fuse = (next_labels is not None and module.training and torch.is_grad_enabled() and frozen and hidden.is_cuda
-            and opted_out and aligned)
+    fuse = next_labels is not None and frozen and hidden.is_cuda and opted_out and aligned
     if fuse:
         loss = ops.lm_head_cross_entropy(hidden, lm_head.weight, next_labels)
         logits = None

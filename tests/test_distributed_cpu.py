@@ -123,6 +123,36 @@ def test_tail_bucket_layout():
         assert b["start"] == eng.offsets[b["members"][0]]
 
 
+def test_default_bucket_size_follows_the_gradient_volume():
+    """bucket_mb=None: an eighth of the flat gradient (1..256 MiB).  A gated-layer-shaped model -- 4 equal layers named
+    neighbor_layers.N, a projection ready last -- gets >= 4 buckets, the first of which closes INSIDE the last layer's backward (it
+    holds only parameters of neighbor_layers.3), so the first all-reduce starts a quarter of the way into backward at the latest."""
+    from mmgl_amd.distributed import DataParallelEngine
+
+    class Layer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1, self.fc2 = torch.nn.Linear(256, 1024), torch.nn.Linear(1024, 256)
+            self.q, self.o = torch.nn.Linear(256, 256), torch.nn.Linear(256, 256)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj = torch.nn.Linear(256, 1024)
+            self.neighbor_layers = torch.nn.ModuleList([Layer() for _ in range(4)])
+
+    eng = DataParallelEngine(Net(), fused=False)
+    total_mb = eng.numel * 4 / (1 << 20)
+    assert abs(eng.bucket_mb - max(1.0, total_mb / 8)) < 1e-9 and eng.tail_mb == min(32.0, eng.bucket_mb)
+    assert len(eng.buckets) >= 4
+    first = [eng.names[i] for i in eng.buckets[0]["members"]]
+    assert all(n.startswith("neighbor_layers.3.") for n in first), first
+    layer3 = sum(p.numel() for n, p in zip(eng.names, eng.params) if n.startswith("neighbor_layers.3."))
+    assert eng.buckets[0]["end"] - eng.buckets[0]["start"] < layer3
+    # explicit sizes are honoured as before
+    assert len(DataParallelEngine(Net(), fused=False, bucket_mb=256, tail_mb=0).buckets) == 1
+
+
 def test_engine_single_process_state_dict_roundtrip():
     from mmgl_amd.distributed import DataParallelEngine
     torch.manual_seed(0)

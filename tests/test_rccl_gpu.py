@@ -94,6 +94,37 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert line["exchange"]["exchange_bytes_per_step_per_gpu"] > 0
 
 
+def test_bench_eight_ranks_launched_as_the_driver_does_gloo():
+    """The N = 8 line of the scaling run, on the ONE GPU a test box has: the driver's own command line (`python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...`) with
+    MMGL_DIST_BACKEND=gloo, all eight ranks on device 0 -- eight different seeded batches, eight engines cutting the same >= 4
+    buckets (layout check at construction), hook-launched all-reduces in index order, barrier + max-over-ranks timing, ONE JSON line
+    from rank 0 as the LAST line of stdout (reference run_generation.py:265-266, 283, 317-319)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MMGL_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "opt-125m", "--batch", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-kernel-timing", "--no-protocol", "--no-batch-sweep", "--ref-batch", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1800)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    json_lines = [l for l in lines if l.startswith('{"metric"')]
+    assert len(json_lines) == 1, f"exactly one JSON line, from rank 0 (got {len(json_lines)})"
+    assert lines[-1] == json_lines[0], "the JSON line is the last line of stdout"
+    line = json.loads(json_lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["parallelism"] == "dp8" and line["config"]["global_batch"] == 16
+    assert line["scaling"] == "weak" and line["value"] > 0 and line["samples_per_sec_per_gpu"] == pytest.approx(line["value"] / 8, rel=1e-3)
+    ex = line["exchange"]
+    assert ex["rccl_ranks"] == 8 and ex["buckets"] >= 4 and ex["exchange_bytes_per_step_per_gpu"] > 0
+    assert ex["wire_bytes_per_step_per_gpu"] == int(2 * 7 / 8 * ex["exchange_bytes_per_step_per_gpu"])
+    assert ex["first_bucket_fraction_of_gradient"] <= 0.25
+
+
 def test_bench_self_launch_refuses_a_mismatched_world(monkeypatch):
     """WORLD_SIZE from a launcher must agree with --gpus: a silent 1-rank run that prints n_gpus = 1 is exactly what the
     scaling measurement must never get."""
