@@ -92,8 +92,10 @@ def test_cider_and_argmax_bf16_hip_vs_fp32_oracle(tmp_path):
         ref_tokens.append(lg.argmax(-1))
         ref_labels.append(lb)
     oracle.cache = list(enc)
+    args.fuse_eval_batches = False                                      # the oracle's encoder cache is per validation batch
     evaluate_loop(loader(), oracle, tokenizer, 0, args, prefix="oracle-fp32")
     ref = dict(evaluate_loop.last)
+    args.fuse_eval_batches = True                                       # the HIP pass below: all 8 batches share one forward (default)
 
     # the bf16 HIP path through the same loop
     hip = model.to(torch.bfloat16).cuda().eval()

@@ -516,3 +516,14 @@ def test_adamw_matches_torch(dtype):
         opt.step()
         ops.adamw_step_(p, master, gr.to(dtype).cuda(), m, v, 1e-2, 0.9, 0.95, 1e-8, 0.01, step)
     assert_close((master if master is not None else p).float().cpu(), pref.detach(), 1e-5, "adamw")
+
+
+def test_stream_ptr_is_torchs_current_stream():
+    """_lib.stream_ptr() (the hipStream_t every C-ABI call is launched on) reads torch's current stream through torch._C directly: it
+    must follow `with torch.cuda.stream(...)` exactly as torch.cuda.current_stream() does."""
+    from mmgl_amd import _lib
+    assert _lib.stream_ptr().value == torch.cuda.current_stream().cuda_stream or (_lib.stream_ptr().value is None and torch.cuda.current_stream().cuda_stream == 0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert _lib.stream_ptr().value == side.cuda_stream
+    assert (_lib.stream_ptr().value or 0) == torch.cuda.current_stream().cuda_stream
