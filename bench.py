@@ -561,6 +561,40 @@ def main():
             protocol[f"{per_device}x{accum}"] = at_protocol(per_device, accum, True, 128 // (per_device * accum), 2)
             protocol[f"{per_device}x{accum}_literal"] = at_protocol(per_device, accum, False, 64 // (per_device * accum), 1)
 
+    # ---- evaluate_loop (reference run_generation.py:527-703) at the reference's per_device_val_batch_size 2: teacher-forced forward,
+    # summary-loss meter, argmax, decode, BLEU / CIDEr over the captions -- several validation batches per forward pass (default)
+    # beside one forward per batch.  Token ids are decoded as numbers (no vocabulary here): the scoring cost is the real one.
+    def at_eval(per_device, n_batches, fuse):
+        from types import SimpleNamespace
+        from mmgl_amd.language_modelling.run_generation import evaluate_loop
+
+        class IdTokenizer:
+            pad_token_id = 1
+
+            def batch_decode(self, ids, skip_special_tokens=True):
+                return [" ".join(str(t) for t in row if t > 2) for row in ids.tolist()]
+
+        mbs = []
+        for i in range(n_batches):
+            hb, _ = synthetic_batch(per_device, cfg, seed=7000 + 100 * rank + i, device=torch.device("cpu"))
+            hb.pop("host_meta")
+            mbs.append({k: v.pin_memory() for k, v in hb.items()})
+        eargs = SimpleNamespace(val_steps_per_epoch=n_batches, print_freq=1 << 30, decoder_only=True, max_input_length=lin,
+                                fuse_eval_batches=fuse, fused_pass_tokens=49152)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            evaluate_loop(mbs[:max(2, n_batches // 4)], model, IdTokenizer(), 0, eargs, prefix="bench-warmup")
+            evaluate_loop(mbs, model, IdTokenizer(), 0, eargs, prefix="bench")
+        model.train()
+        return {"per_device_val_batch_size": per_device, "batches": n_batches, "batches_share_a_forward": fuse,
+                "value": round(world * evaluate_loop.samples_per_sec, 3), "unit": "samples/s"}
+
+    eval_line = None
+    if not args.no_protocol and cfg["kind"] == "flamingo":
+        eval_line = {"through": "mmgl_amd.language_modelling.run_generation.evaluate_loop (incl. decode + BLEU / CIDEr scoring on the host)",
+                     "grouped": at_eval(2, 64, True), "literal": at_eval(2, 32, False)}
+
     ref_line = None
     if args.ref_batch and args.ref_batch < args.batch:
         ref_line = at_batch(args.ref_batch, 4321, 3, 10)
@@ -679,6 +713,8 @@ def main():
             line["hip_path_ms_per_step"] = round(sum(s["ms_total"] for s in ks.values()) / table_steps, 2)
         if protocol is not None:
             line["at_reference_protocol"] = protocol
+        if eval_line is not None:
+            line["evaluate_loop"] = eval_line
         if ref_line is not None:
             line["at_reference_batch"] = ref_line
         if sweep is not None:

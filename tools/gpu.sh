@@ -8,7 +8,7 @@
 #   bench[:<config>[:<extra bench.py flags, comma separated>]]                      -> bench_<config>.json (the JSON line) + .log
 #   prof[:<config>[:<flags>]]  rocprofv3 --kernel-trace --stats of a short bench    -> prof_<config>_kernel_stats.csv
 #   py:<script>[:<args,comma separated>]   python <script> args                     -> <script basename>.log
-#   sh:<command with _ for spaces>         arbitrary shell                          -> sh.log
+#   sh:<command with + for spaces>         arbitrary shell                          -> sh.log
 set -u
 tag=$1; shift
 O=gpurun_out/$tag; mkdir -p $O
@@ -39,7 +39,7 @@ PY
             timeout 1500 rocprofv3 --kernel-trace --stats -d /tmp/prof_$c -o p -f csv -- python bench.py --config $c --steps 6 --warmup 2 --no-cpu-baseline --no-batch-sweep --no-protocol --ref-batch 0 ${b//,/ } > $O/prof_$c.log 2>&1
             f=$(find /tmp/prof_$c -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/prof_${c}_kernel_stats.csv && head -12 $O/prof_${c}_kernel_stats.csv | cut -c1-160;;
     py)     n=$(basename $a .py); timeout 1500 python $a ${b//,/ } > $O/$n.log 2>&1; echo "[py $n] rc $?"; tail -40 $O/$n.log;;
-    sh)     timeout 1500 bash -c "${a//_/ }" > $O/sh.log 2>&1; echo "[sh] rc $?"; tail -20 $O/sh.log;;
+    sh)     timeout 1500 bash -c "${a//+/ }" > $O/sh.log 2>&1; echo "[sh] rc $?"; tail -20 $O/sh.log;;
     *)      echo "unknown task $task";;
   esac
 done
