@@ -558,8 +558,11 @@ def main():
     if not args.no_protocol and cfg["kind"] in ("flamingo", "lora"):
         protocol = {"through": "mmgl_amd.language_modelling.run_generation.train_loop (host micro-batches in pinned memory, H2D inside)"}
         for per_device, accum in ((4, 4), (2, 16)):
-            protocol[f"{per_device}x{accum}"] = at_protocol(per_device, accum, True, 128 // (per_device * accum), 2)
-            protocol[f"{per_device}x{accum}_literal"] = at_protocol(per_device, accum, False, 64 // (per_device * accum), 1)
+            # warm-up = one pass over the SAME micro-batches (the packed encoder buffers have data-dependent sizes: the first time a
+            # group's shapes are seen the caching allocator grows -- hipMalloc, a device sync -- which a 2000-step epoch amortises)
+            n_f, n_l = 256 // (per_device * accum), 64 // (per_device * accum)
+            protocol[f"{per_device}x{accum}"] = at_protocol(per_device, accum, True, n_f, n_f)
+            protocol[f"{per_device}x{accum}_literal"] = at_protocol(per_device, accum, False, n_l, n_l)
 
     # ---- evaluate_loop (reference run_generation.py:527-703) at the reference's per_device_val_batch_size 2: teacher-forced forward,
     # summary-loss meter, argmax, decode, BLEU / CIDEr over the captions -- several validation batches per forward pass (default)

@@ -21,8 +21,8 @@ template <typename T, int D_, int NSB_, int WORK_ = 1> struct XC {
     static constexpr int NKS = NSB / 2;              // 32-key contraction steps
     static constexpr int SPAD = NSB * 16;
     static constexpr int CPR = DPAD / 8;             // 8-element chunks per (padded) row
-#ifdef MMGL_XATTN_QT_FORCE
-    static constexpr int QT = MMGL_XATTN_QT_FORCE;
+#ifdef MMGL_XATTN_QT_FORCE                           // (experiments: the forward kernel only -- the fused backward needs 32-row tiles)
+    static constexpr int QT = (WORK_ == 1) ? MMGL_XATTN_QT_FORCE : ((WORK_ * NSB_ * (D_ / 16) * (int)(sizeof(T) / 2) <= 32) ? 2 : 1);
 #else
     static constexpr int QT = (WORK_ * NSB_ * (D_ / 16) * (int)(sizeof(T) / 2) <= 32) ? 2 : 1;
 #endif

@@ -1172,12 +1172,20 @@ int tune_env(const char* name, int dflt) {
 }
 
 // rows_per_wg / nchunk: about `target` workgroups in flight (all resident in one round: 2-5 per CU), each workgroup a
-// whole number of 4-wave tile rounds where possible.
+// whole number of 4-wave tile rounds where possible -- and never ONE workgroup per (batch, head) when the rows allow two: with
+// B H >= 1024 equal workgroups the launch is whole rounds of identical workgroups that stage K / V at the same moment and drain
+// their last stores at the same moment (4 per CU at D = 64: 2048 pairs = two rounds).  Two workgroups per pair (K / V staged twice,
+// the second time out of L2): 92.1 -> 85.5 us at B = 64 on one box, 87.4 -> 82.8 on another (round 6,
+// profiles/r6_xattn_fwd_chunks_sweep.txt).  Measured and NOT adopted: three / four / six per pair (83.5 / 88 / 94), two of unequal
+// length (55 / 60 / 70 % of the rows in the first: 87.5 / 90.8 / 99.5 -- the long ones set the tail), 16-row tiles per wave with
+// five or six workgroups per CU (88-89).
 void fwd_geometry(int B, int H, int T, int tile_rows, int& rows_per_wg, int& nchunk) {
     static const int target = tune_env("MMGL_XATTN_TARGET_WGS", 512);
+    static const int min_chunks = tune_env("MMGL_XATTN_MIN_CHUNKS", 2);
     const int bh = B * H;
     int nc = (target + bh / 2) / bh;
     const int maxc = (T + tile_rows - 1) / tile_rows;
+    if (nc < min_chunks && T >= 8 * tile_rows) nc = min_chunks;
     if (nc > maxc) nc = maxc;
     if (nc < 1) nc = 1;
     int rows = ((T + nc - 1) / nc + tile_rows - 1) / tile_rows * tile_rows;
