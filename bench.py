@@ -322,7 +322,7 @@ def pmc_traffic(B, lm_cfg, cfg, dtype):
     separate passes, gfx950 x2 fetch correction applied: profiles/r<round>_pmc_xattn_*.json) when it was taken at this exact
     shape, and the file it came from; (None, None) otherwise -- PMC counters cannot be read from inside this process, so `traffic` is
     a committed measurement of the same kernel at the same shape, NOT a counter of this run (`traffic_source` says which file)."""
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):                     # the latest round's collection first
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):                     # the latest round's collection first
         rel = os.path.join("profiles", f"{rnd}_pmc_xattn_B{B}_{dtype}.json")
         try:
             with open(os.path.join(ROOT, rel)) as f:
