@@ -701,6 +701,15 @@ def main():
                 gb = alg_b / (xb["ms_avg"] * 1e-3) / 1e9
                 kern["mmgl_xattn_bwd"].update(bound="hbm", gbs=round(gb, 1), frac=round(gb / HBM_PEAK_GBS, 4))
             line["kernels"] = kern
+            # what bounds the MFMA entries above (a committed measurement of this kernel, not a counter of this run): per 256x256 tile
+            # t = a K + X -- the steady state of the ping-pong phases plus a K-independent tile boundary; the L2->LDS operand path is at
+            # 0.20-0.30 of its 63.6 B/clk/CU at every shape (tools/probes/gemm_tile_model.py)
+            kdim = lm_cfg.hidden_size
+            line["gemm_bound"] = {"source": "profiles/r6_gemm_tile_model.txt", "kernel": "gemm8p_kernel (mmgl_gemm_nt / mmgl_linear_*)",
+                                  "bound": "mfma steady state (0.55-0.62 of the nominal-clock pipe: 1.8 GHz sustained x ping-pong phases) + "
+                                           "tile boundary (3.3-5.9 us per 256x256 tile); lds-dma operand path 0.20-0.30 utilised",
+                                  "ceiling_frac_of_peak_by_K": {"768": [0.42, 0.51], "2048": [0.50, 0.56], "3072": [0.51, 0.58], "8192": [0.54, 0.60]},
+                                  "this_config_K": [kdim, getattr(lm_cfg, "ffn_dim", None) or getattr(lm_cfg, "intermediate_size", None)]}
             # BASELINE.json's second metric, "cross-attn TFLOPS % of peak": every mmgl_linear_* call of this step belongs to the
             # gated cross-attention layers (projections + FFN; the frozen layers' GEMMs go through mmgl_gemm_nt), so the layer-level
             # rate is (their FLOPs + the attention core's) / (their time + the core's time), forward and backward.
