@@ -208,3 +208,45 @@ def test_fusion_is_declined_when_the_means_would_differ():
     assert not _fusable(m, args, [mb, mb])
     assert _pass_sizes(16, 2, 640, 49152) == [16] and _pass_sizes(16, 4, 2176, 49152) == [4, 4, 4, 4]
     assert _pass_sizes(16, 2, 640, 9 * 1280) == [8, 8] and _pass_sizes(3, 64, 640, 49152) == [1, 1, 1]
+
+
+def _two_rank_fused_worker(rank, world, port, tmp):
+    from types import SimpleNamespace
+    from mmgl_amd.distributed import DataParallelEngine
+    from mmgl_amd.language_modelling.run_generation import train_loop
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    model = _ToyCausalLM().double()
+    B, T, accum, n_micro = 2, 12, 4, 10                 # groups of 4, 4 and a short 2; every group cut into passes of <= 2 micro-batches
+    g = torch.Generator().manual_seed(100 + rank)
+    batches = []
+    for _ in range(n_micro):
+        ids = torch.randint(2, 23, (B, T), generator=g)
+        batches.append(dict(input_ids=ids, attention_mask=torch.ones(B, T, dtype=torch.long), labels=ids.clone()))
+    args = SimpleNamespace(steps_per_epoch=n_micro, grad_accumulation_steps=accum, decoder_only=True, max_input_length=T - 6, print_freq=1,
+                           per_device_train_batch_size=B, fuse_grad_accumulation=True, fused_pass_tokens=2 * B * T)
+    engine = DataParallelEngine(model, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01, fused=False, bucket_mb=0.001, tail_mb=0)
+    hist = train_loop(batches, model, None, engine, 0, WarmupStepLR(1e-2, 2, 2, 0.5), args)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    if rank == 0:
+        torch.save(dict(same=bool(torch.equal(both[0], both[1])), passes=[h["passes"] for h in hist], exchange=engine.exchange_bytes,
+                        numel=engine.numel, esize=engine.flat_grad.element_size(), buckets=len(engine.buckets), steps=engine.step_count,
+                        batches=batches, params=flat), os.path.join(tmp, "fused.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_fused_groups_exchange_once_per_optimizer_step(tmp_path):
+    """N > 1 with the accumulation group cut into several passes: gradients cross the wire on the LAST pass of a group only (one
+    exchange of the whole flat gradient per optimizer step, several buckets), both ranks end bit-identical."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_rank_fused_worker, nprocs=2, args=(2, port, str(tmp_path)), join=True)
+    out = torch.load(str(tmp_path / "fused.pt"), weights_only=False)
+    assert out["same"], "ranks diverged"
+    assert out["passes"] == [[2, 2], [2, 2], [2]] and out["steps"] == 3 and out["buckets"] >= 2
+    assert out["exchange"] == 3 * out["numel"] * out["esize"]
