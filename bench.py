@@ -555,7 +555,8 @@ def main():
                 "ms_per_optimizer_step": round(1e3 * t1 / n_opt, 3), "optimizer_steps": n_opt}
 
     protocol = None
-    if not args.no_protocol and cfg["kind"] in ("flamingo", "lora"):
+    # (single-GPU diagnostics: the N > 1 lines of the scaling run carry `value`, `exchange` and the sweep only)
+    if not args.no_protocol and world == 1 and cfg["kind"] in ("flamingo", "lora"):
         protocol = {"through": "mmgl_amd.language_modelling.run_generation.train_loop (host micro-batches in pinned memory, H2D inside)"}
         for per_device, accum in ((4, 4), (2, 16)):
             # warm-up = one pass over the SAME micro-batches (the packed encoder buffers have data-dependent sizes: the first time a
@@ -594,7 +595,7 @@ def main():
                 "value": round(world * evaluate_loop.samples_per_sec, 3), "unit": "samples/s"}
 
     eval_line = None
-    if not args.no_protocol and cfg["kind"] == "flamingo":
+    if not args.no_protocol and world == 1 and cfg["kind"] == "flamingo":
         eval_line = {"through": "mmgl_amd.language_modelling.run_generation.evaluate_loop (incl. decode + BLEU / CIDEr scoring on the host)",
                      "grouped": at_eval(2, 64, True), "literal": at_eval(2, 32, False)}
 
