@@ -556,12 +556,14 @@ def main():
 
     protocol = None
     # (single-GPU diagnostics: the N > 1 lines of the scaling run carry `value`, `exchange` and the sweep only)
-    if not args.no_protocol and world == 1 and cfg["kind"] in ("flamingo", "lora"):
+    if not args.no_protocol and world == 1:
         protocol = {"through": "mmgl_amd.language_modelling.run_generation.train_loop (host micro-batches in pinned memory, H2D inside)"}
         for per_device, accum in ((4, 4), (2, 16)):
             # warm-up = one pass over the SAME micro-batches (the packed encoder buffers have data-dependent sizes: the first time a
             # group's shapes are seen the caching allocator grows -- hipMalloc, a device sync -- which a 2000-step epoch amortises)
             n_f, n_l = 256 // (per_device * accum), 64 // (per_device * accum)
+            if cfg["kind"] == "llama":                # 2176-token samples: ~0.85 s per 16 of them
+                n_f, n_l = 2, 1
             protocol[f"{per_device}x{accum}"] = at_protocol(per_device, accum, True, n_f, n_f)
             protocol[f"{per_device}x{accum}_literal"] = at_protocol(per_device, accum, False, n_l, n_l)
 
