@@ -174,8 +174,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
 }
 template <typename T> __device__ __forceinline__ typename Elem<T>::v8 buf_load8(__amdgpu_buffer_rsrc_t r, uint32_t off);
+#ifndef ATTN_LOAD_AUX
+#define ATTN_LOAD_AUX 0          // cache policy bits of the streamed Q / dO row loads (2 = nt, 16 = sc1): timing experiments
+#endif
 template <> __device__ __forceinline__ bf16x8 buf_load8<bf16>(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, ATTN_LOAD_AUX));
 }
 template <> __device__ __forceinline__ f32x8 buf_load8<float>(__amdgpu_buffer_rsrc_t r, uint32_t off) {
     const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
