@@ -8,10 +8,12 @@
     once per optimizer step, overlapped with backward, fused AdamW kernel;
   * "mpt" model names (or peft_type flamingo) select CrossAttentionModel exactly as :286-301 dispatch on substrings;
   * `neighbor_layer_wise` exists (the reference reads it but never defines it, SURVEY.md 3.4);
-  * the step loop reproduces :462-524: loss / accum, backward every micro-batch, step + scheduler every
-    `grad_accumulation_steps`, NO gradient clipping unless grad_clip > 2 (:492), meters all-reduced every print_freq
-    optimizer steps, examples_per_sec = per_device_batch / batch_time * n_gpus (:503) -- with a device sync before the
-    clock is read;
+  * the step loop reproduces :462-524: loss / accum, step + scheduler every `grad_accumulation_steps`, NO gradient clipping
+    unless grad_clip > 2 (:492), meters all-reduced every print_freq optimizer steps, examples_per_sec = per_device_batch /
+    batch_time * n_gpus (:503) -- batch_time from HIP events, resolved when the meters are read (_Meters);
+  * the `grad_accumulation_steps` micro-batches of one optimizer step run as ONE forward / backward pass over the concatenated
+    samples when that is the same number (train_loop, _fusable; `fuse_grad_accumulation=False` = one pass per micro-batch);
+    evaluate_loop shares a forward pass between validation batches the same way;
   * validation CIDEr / BLEU on teacher-forced argmax tokens (:604-606), predictions all-gathered (:608-616);
   * checkpoint dict layout of :402-416 (frozen encoders stripped, `module.` prefix kept) so checkpoints interchange.
 wandb / torchmetrics / warmup_scheduler are absent here: logging goes to stdout, BLEU is a local corpus-BLEU,
