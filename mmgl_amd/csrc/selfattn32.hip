@@ -345,21 +345,39 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
     const long long tr1 = wall_clock64();
     long long tr2 = tr1;
 #endif
+    // ---- the LIVE key tiles of this workgroup (round 6).  A tile whose 64 keys are all padding contributes nothing; until round 5 it
+    // was still fetched (LDS-DMA), waited for and barriered, only its arithmetic was skipped -- and the kernel is bound by exactly
+    // that traffic and latency, not by the arithmetic.  WikiWeb2M prompts are padded to max_input_length (data.py:320-321): on the
+    // synthetic batches ~45 % of the key tiles a late query block walks are dead.  bit j of `live` <=> tile j has an attendable key;
+    // the NPRO tiles requested by the prologue (before the mask bytes were known) stay in the walk whatever their words say.
+    constexpr int NPRO = EARLY ? 2 : PD;
+    uint64_t live = __builtin_amdgcn_ballot_w64(lane < nkt && vbits[min(lane, nkt - 1)] != 0ull);
+    live |= (1ull << NPRO) - 1ull;
+    if (nkt < 64) live &= (1ull << nkt) - 1ull;
+    const int nlive = __builtin_popcountll(live);
+    uint64_t rem = live & (live - 1ull);                                // tiles still to walk after tile j (= 0, forced live)
+    uint64_t irem = live & ~((1ull << NPRO) - 1ull);                    // live tiles not yet requested
+    int j = 0;
     uint64_t vm = vbits[0];
     int slot = 0, islot = PD % G::NS;
-    for (int j = 0; j < nkt; ++j) {
+    for (int c = 0; c < nlive; ++c) {
 #if SA32_TRACE
-        if (j == 1) tr2 = wall_clock64();
+        if (c == 1) tr2 = wall_clock64();
 #endif
-        // tile j has landed (this wave's pieces: all but the NP * (tiles still in flight behind it) youngest loads), then everybody's
-        if (EARLY ? j == 0 : (PD >= 2 && j + 1 < nkt)) {
+        // walk step c has landed (this wave's pieces: all but the NP * (tiles still in flight behind it) youngest loads), then everybody's
+        if (EARLY ? c == 0 : (PD >= 2 && c + 1 < nlive)) {
             if (G::NP == 4) SA32_VMCNT(4); else SA32_VMCNT(8);
         } else {
             SA32_VMCNT(0);
         }
         SA32_BARRIER();
-        if (j + PD < nkt && !(EARLY && j == 0)) issue(j + PD, islot);
-        const uint64_t vnext = vbits[min(j + 1, nkt - 1)];
+        if (irem != 0ull && !(EARLY && c == 0)) {
+            issue(__builtin_ctzll(irem), islot);
+            irem &= irem - 1ull;
+        }
+        const int jn = rem != 0ull ? __builtin_ctzll(rem) : j;
+        rem &= rem - 1ull;
+        const uint64_t vnext = vbits[jn];
         const uint32_t vlo = __builtin_amdgcn_readfirstlane((uint32_t)vm), vhi = __builtin_amdgcn_readfirstlane((uint32_t)(vm >> 32));
         if (j <= jlast && (vlo | vhi) != 0u) {
             const bool mixed = (vlo & vhi) != 0xffffffffu;
@@ -367,6 +385,7 @@ __global__ __launch_bounds__(256, G32<D>::OCC) void sa32_fwd_kernel(SA32Args a) 
             // the block steps at T = 640; as a second inlined body it costs 42 VGPRs and 48 accumulator copies per tile)
             body(std::integral_constant<int, 2>(), j, vlo, vhi, mixed, slot);
         }
+        j = jn;
         vm = vnext;
         slot = (slot + 1 == G::NS) ? 0 : slot + 1;
         islot = (islot + 1 == G::NS) ? 0 : islot + 1;
@@ -628,16 +647,31 @@ __global__ __launch_bounds__(256, SA32_DQ_OCC) void sa32_bwd_dq_kernel(SA32BwdAr
     };
 
     SA32_BARRIER();
+    // the live key tiles only (see the forward kernel): dead tiles are neither fetched nor waited for
+    constexpr int NPRO = EARLY ? 2 : PD;
+    uint64_t live = __builtin_amdgcn_ballot_w64(lane < nkt && vbits[min(lane, nkt - 1)] != 0ull);
+    live |= (1ull << NPRO) - 1ull;
+    if (nkt < 64) live &= (1ull << nkt) - 1ull;
+    const int nlive = __builtin_popcountll(live);
+    uint64_t rem = live & (live - 1ull);
+    uint64_t irem = live & ~((1ull << NPRO) - 1ull);
+    int j = 0;
     uint64_t vm = vbits[0];
     int slot = 0, islot = PD % NS;
-    for (int j = 0; j < nkt; ++j) {
-        if (EARLY ? j == 0 : (PD >= 2 && j + 1 < nkt)) { if (G::NP == 4) SA32_VMCNT(4); else SA32_VMCNT(8); }       // tile j landed, tile j + 1 may be in flight
+    for (int c = 0; c < nlive; ++c) {
+        if (EARLY ? c == 0 : (PD >= 2 && c + 1 < nlive)) { if (G::NP == 4) SA32_VMCNT(4); else SA32_VMCNT(8); }       // step c landed, step c + 1 may be in flight
         else SA32_VMCNT(0);
         SA32_BARRIER();
-        if (j + PD < nkt && !(EARLY && j == 0)) issue(j + PD, islot);
-        const uint64_t vnext = vbits[min(j + 1, nkt - 1)];
+        if (irem != 0ull && !(EARLY && c == 0)) {
+            issue(__builtin_ctzll(irem), islot);
+            irem &= irem - 1ull;
+        }
+        const int jn = rem != 0ull ? __builtin_ctzll(rem) : j;
+        rem &= rem - 1ull;
+        const uint64_t vnext = vbits[jn];
         const uint32_t vlo = __builtin_amdgcn_readfirstlane((uint32_t)vm), vhi = __builtin_amdgcn_readfirstlane((uint32_t)(vm >> 32));
         if (j <= jlast && (vlo | vhi) != 0u) body(j, vlo, vhi, (vlo & vhi) != 0xffffffffu, slot);
+        j = jn;
         vm = vnext;
         slot = (slot + 1 == NS) ? 0 : slot + 1;
         islot = (islot + 1 == NS) ? 0 : islot + 1;
@@ -849,19 +883,28 @@ __global__ __launch_bounds__(256, D == 64 ? SA32_DKV_OCC64 : 1) void sa32_bwd_dk
         }
     };
 
+    // A workgroup whose 128 keys are ALL padding (round 6): its dK / dV are zero.  Until round 5 it still walked every query tile
+    // (LDS-DMA, waits, barriers; only the arithmetic was skipped per wave).  The four waves exchange their ballots through the unused
+    // tail of ring slot 0 behind one extra barrier; a dead workgroup's loop has no trips (a `break` out of the loop instead moved the
+    // D = 128 accumulators into AGPRs: 304 -> 408 registers, +27 % time) and the epilogue stores the zero accumulators.
+    int* wflag = (int*)(smem + 2 * G::TILEB + 512);
+    if (lane == 0) wflag[wave] = wave_has_keys ? 1 : 0;
+    SA32_BARRIER();
+    const bool wg_dead = __builtin_amdgcn_readfirstlane(wflag[0] | wflag[1] | wflag[2] | wflag[3]) == 0;
+    const int nqe = wg_dead ? i0 : nqt;                                 // workgroup-uniform
     int slot = 0, islot = PD % NS;
-    for (int i = i0; i < nqt; ++i) {
-        if (EARLY ? i == i0 : (PD >= 2 && i + 1 < nqt)) { if (GB::NPB == 6) SA32_VMCNT(6); else SA32_VMCNT(10); }     // tile i landed, tile i + 1 may be in flight
+    for (int i = i0; i < nqe; ++i) {
+        if (EARLY ? i == i0 : (PD >= 2 && i + 1 < nqe)) { if (GB::NPB == 6) SA32_VMCNT(6); else SA32_VMCNT(10); }     // tile i landed, tile i + 1 may be in flight
         else SA32_VMCNT(0);
         SA32_BARRIER();
-        if (i + PD < nqt && !(EARLY && i == i0)) issue(i + PD, islot);
+        if (i + PD < nqe && !(EARLY && i == i0)) issue(i + PD, islot);
         // this wave's keys are seen by some row of the tile iff its first key k0 <= last row + P
         if (wave_has_keys && k0 <= i * 64 + 63 + a.P) body(i, slot);
         slot = (slot + 1 == NS) ? 0 : slot + 1;
         islot = (islot + 1 == NS) ? 0 : islot + 1;
     }
 
-    if (EARLY) SA32_VMCNT(0);
+    if (EARLY || wg_dead) SA32_VMCNT(0);                                 // (the prologue's requests must not outlive the workgroup's LDS)
     // ---- epilogue: dK = -acc, dV rows (lane = key row: the forward kernel's output store)
     const uint32_t orow = (krow < Tk) ? (uint32_t)krow * ldgB : OOB;
 #pragma unroll

@@ -79,6 +79,42 @@ def test_selfattn_causality_and_determinism():
     assert torch.equal(g1, g2)
 
 
+@pytest.mark.parametrize("B,H,T,D", [(3, 4, 640, 64), (2, 2, 2176, 128)])
+def test_selfattn_dead_key_tiles_are_never_touched(B, H, T, D):
+    """Key tiles whose 64 keys are all padding leave the walk of the forward and dQ kernels, key blocks whose 128 keys are all padding
+    leave the dK / dV launch (round 6; WikiWeb2M pads every prompt to max_input_length, reference wikiweb2m/data.py:320-321).  NaNs in
+    the K / V rows of fully dead tiles must not reach any output (a tile that is fetched and multiplied by zero probabilities would
+    turn them into NaN), outputs and gradients are bit-identical to the clean run, dK / dV of padded keys are exactly zero."""
+    from mmgl_amd import ops
+    gen = torch.Generator().manual_seed(B + T)
+    d = H * D
+    q, k, v, w = ((torch.randn(B, T, d, generator=gen) * s).bfloat16().cuda() for s in (0.3, 1.0, 1.0, 1.0))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[0, 70:T - 128] = 0                     # prompt | pad ... | summary: mixed tile 64..127, dead tiles 128 .. T-129
+    am[0, T - 40:] = 0
+    am[1, 200:] = 0                           # everything after the prompt is padding
+    dead = torch.zeros(B, T, dtype=torch.bool)
+    dead[0, 128:T - 128] = True
+    dead[1, 256:] = True
+    am_d = am.cuda()
+
+    def run(kk, vv):
+        qq, kk, vv = (t.clone().requires_grad_() for t in (q, kk, vv))
+        o = ops.selfattn_core(qq, kk, vv, am_d, H)
+        return (o,) + torch.autograd.grad((o * w).sum(), (qq, kk, vv))
+
+    clean = run(k, v)
+    kp, vp = k.clone(), v.clone()
+    kp[dead.cuda()] = float("nan")
+    vp[dead.cuda()] = float("nan")
+    poisoned = run(kp, vp)
+    for name, a, b in zip(("out", "dq", "dk", "dv"), clean, poisoned):
+        assert torch.isfinite(b).all(), f"{name}: a dead key tile was touched"
+        assert torch.equal(a, b), name
+    pad = ~am.bool().cuda()
+    assert (clean[2][pad] == 0).all() and (clean[3][pad] == 0).all()
+
+
 @pytest.mark.parametrize("B,H,T,D", CASES)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_selfattn_fused_qkv_is_bitwise_the_separate_path(B, H, T, D, dtype):
