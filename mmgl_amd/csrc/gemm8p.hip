@@ -669,6 +669,10 @@ void gemm8p_plan(int M, int N, int K, int* direct, int* nsplit) {
     if (tiles < 160) {
         constexpr int min_units = 24;                     // K >= 3072 (tools: 2560 x 2048 x K sweep)
         if (units < min_units) return;
+        // K in [3072, 4096) with >= 64 tiles (config 2's fc2 / fc1-dgrad at B = 16: 10240 x 768 x 3072 = 120 tiles): two K splits of
+        // 12 units each plus the fp32 fold (66.6 + 13.1 us) lose to the 128x128 kernel, whose 480 tiles fill 94 % of its slots:
+        // config 2 at B = 16 946 -> 963 samples/s, B = 4 / B = 64 unchanged (round 6, tools/probes/ab_bench.sh)
+        if (units < 32 && tiles >= 64) return;
         int s = (224 + tiles - 1) / tiles;
         if (s > 8) s = 8;
         if (s > units / 2) s = units / 2;

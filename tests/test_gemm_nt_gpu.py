@@ -43,7 +43,8 @@ CASES = [
     (4099, 4096, 11008, 4, True, True, True, 1.0),       # config-5 dims, tanh-GELU, everything at once
     (2560, 2048, 8192, 1, True, False, False, 1.0),      # the reference's batch of 4 (80 tiles): K-split work items + finish kernel
     (2600, 2048, 6144, 3, True, True, False, 0.5),       # uneven K splits (48 steps over 3), ragged M, residual, scale
-    (2560, 2064, 3072, 0, False, False, True, 1.0),      # K split with a ragged last column tile and the zmask applied by the finish kernel
+    (2560, 2064, 4096, 0, False, False, True, 1.0),      # K split with a ragged last column tile and the zmask applied by the finish kernel
+    (2560, 2064, 3072, 0, False, False, True, 1.0),      # same at K = 3072: 90 tiles -> the 128x128 kernel since round 6 (gemm8p_plan)
     (2560, 8192, 2048, 1, True, False, False, 1.0),      # 320 tiles on 256 CUs: 2048 rows = one round of the persistent kernel + 512 tail rows on the few-tile kernel
     (2560, 8192, 2048, 0, True, True, True, 0.5),        # the same row split with zmask + residual (both offset to the tail rows) and a scale
     (2400, 8192, 2048, 1, True, True, True, 1.0),        # the row split with a ragged tail (2048 + 352 rows), every epilogue stage
