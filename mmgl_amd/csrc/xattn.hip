@@ -809,9 +809,6 @@ __global__ __launch_bounds__(64) void xattn_bwd_fused_kernel(const bf16* __restr
 // workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. the Q / dO rows requested two
 // tiles ahead and the dQ stores of the previous tile, three times per tile
 #define XW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#ifndef XW_SETS
-#define XW_SETS 2                  // register sets of Q / dO rows in flight per wave (tiles requested ahead)
-#endif
 template <int D, int NSB>
 __global__ __launch_bounds__(32 * NSB) void xattn_bwd_fusedw_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ q,
                                                                     const bf16* __restrict__ k, const bf16* __restrict__ v,
@@ -859,10 +856,6 @@ __global__ __launch_bounds__(32 * NSB) void xattn_bwd_fusedw_kernel(const bf16* 
     // and scaled at the top of a step, hipcc rotated them with v_mov behind s_waitcnt vmcnt(0) at the back edge -- the prefetch drained)
     v8 qA[IPW], gA[IPW], qB[IPW], gB[IPW];
     uint32_t lA, lB;
-#if XW_SETS == 3
-    v8 qC[IPW], gC[IPW];                           // third set: three tiles (48 KiB per workgroup at D = 128) in flight instead of two
-    uint32_t lC;
-#endif
     auto request = [&](int tbase, v8 (&qn)[IPW], v8 (&gn)[IPW], uint32_t& lsn) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < IPW; ++j) {
@@ -875,9 +868,6 @@ __global__ __launch_bounds__(32 * NSB) void xattn_bwd_fusedw_kernel(const bf16* 
     };
     request(row_begin, qA, gA, lA);
     request(row_begin + 32, qB, gB, lB);
-#if XW_SETS == 3
-    request(row_begin + 64, qC, gC, lC);
-#endif
 
     // K and V of this wave's keys live in REGISTERS for the whole chunk (one wave per SIMD: the register file is there, the LDS port
     // is the scarce resource -- re-reading them every tile was 96 of the 312 KiB a tile moved through LDS):
@@ -1013,7 +1003,7 @@ __global__ __launch_bounds__(32 * NSB) void xattn_bwd_fusedw_kernel(const bf16* 
         }
         if (wave == 0 && lane < 32) ((uint32_t*)LSEt)[par * 32 + lane] = lsn;
         XW_BARRIER();                                         // [B1] the tile's Q / dO rows are in LDS
-        request(t0 + 32 * XW_SETS, qn, gn, lsn);              // this set's registers are free: XW_SETS tiles ahead
+        request(t0 + 64, qn, gn, lsn);                        // this set's registers are free: the tile after next
         float l2[2];                                          // rows past T: Q = dO = 0 and lse reads 0 -> finite p, dP = 0, dS = 0
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) l2[qt] = LSEt[par * 32 + qt * 16 + x] * LOG2E;
@@ -1104,22 +1094,10 @@ __global__ __launch_bounds__(32 * NSB) void xattn_bwd_fusedw_kernel(const bf16* 
     // Both register sets every trip (row_end is uniform over the workgroup: every wave takes every barrier).  A chunk of an odd number
     // of tiles runs one empty tile (loads fall outside the descriptor, p = 0, nothing stored): with the second step conditional, hipcc
     // resolves the loop-carried lse registers with a v_mov behind s_waitcnt vmcnt(0) -- the whole prefetch drained every trip.
-#if XW_SETS == 3
-    // three register sets in a fixed order (no rotation: see above); three steps flip the LDS tile's parity, so it is a loop-carried
-    // scalar; a chunk runs up to two empty tiles
-    int par0 = 0;
-    for (int t0 = row_begin; t0 < row_end; t0 += 96) {
-        step(t0, par0, qA, gA, lA);
-        step(t0 + 32, par0 ^ 1, qB, gB, lB);
-        step(t0 + 64, par0, qC, gC, lC);
-        par0 ^= 1;
-    }
-#else
     for (int t0 = row_begin; t0 < row_end; t0 += 64) {
         step(t0, 0, qA, gA, lA);
         step(t0 + 32, 1, qB, gB, lB);
     }
-#endif
     flush();                                                  // the last tile's dQ
 
 #pragma unroll
